@@ -1,0 +1,163 @@
+/*
+ * gsr.h -- C ABI of libgsr.so: the MI355X (gfx950) articulated Gaussian-splat hot path.
+ *
+ * Drop-in boundary.  Every entry point replaces one interface of the reference
+ * (paths relative to the reference tree; DGR = submodules/diff-gaussian-rasterization,
+ * CR = DGR/cuda_rasterizer, SK = submodules/simple-knn):
+ *
+ *   gsr_rasterize_forward   <- CudaRasterizer::Rasterizer::forward      CR/rasterizer.h:32-56, CR/rasterizer_impl.cu:198-341
+ *   gsr_rasterize_backward  <- CudaRasterizer::Rasterizer::backward     CR/rasterizer.h:58-89, CR/rasterizer_impl.cu:345-447
+ *   gsr_mark_visible        <- CudaRasterizer::Rasterizer::markVisible  CR/rasterizer.h:25-30, CR/rasterizer_impl.cu:141-153
+ *   gsr_dist2               <- SimpleKNN::knn                           SK/simple_knn.h:17, SK/simple_knn.cu:185-221
+ *   gsr_lbs_*               <- GaussianModel.coarse_deform_c2source     scene/gaussian_model.py:768-872
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is enqueued on it;
+ *   - the three growable scratch buffers of the reference (geometry / binning / image state,
+ *     std::function<char*(size_t)> callbacks in CR/rasterizer.h:33-35) are requested through
+ *     gsr_alloc_fn callbacks: the library calls alloc(user, bytes) once per buffer per forward call
+ *     and the caller returns a device pointer that stays valid until the matching backward;
+ *     the contents are private to the library;
+ *   - a null `shs` / `colors_precomp` / `scales` / `rotations` / `cov3D_precomp` pointer selects the
+ *     other input mode exactly like the reference (CR/forward.cu:205,241);
+ *   - every function returns GSR_OK (0) or a negative GSR_E* code; gsr_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.  With debug != 0 the
+ *     library synchronises and checks after every kernel (CR/auxiliary.h:166-173).
+ */
+#ifndef GSR_H_INCLUDED
+#define GSR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_EINVAL (-1)  /* bad argument (shape/size/null) */
+#define GSR_EHIP (-2)    /* a HIP runtime call or kernel failed */
+#define GSR_ENOMEM (-3)  /* an allocation callback returned null / workspace too small */
+
+typedef void *gsr_stream_t;
+typedef char *(*gsr_alloc_fn)(void *user, size_t bytes);
+
+/* Library version (major*10000 + minor*100 + patch) and the gfx target it was built for ("gfx950"). */
+int gsr_version(void);
+const char *gsr_target_arch(void);
+const char *gsr_last_error(void);
+
+/* Binning back-ends (gsr_set_binning_mode): both produce bit-identical point lists and tile ranges.
+ *   GSR_BINNING_GLOBAL_RADIX: duplicate keys + device-wide stable LSD radix sort on the low 32+bit key bits +
+ *                             identifyTileRanges -- the reference's structure (CR/rasterizer_impl.cu:291-320);
+ *   GSR_BINNING_TILE_BUCKET : per-tile counting + per-tile LDS sort on (depth bits, Gaussian id). */
+#define GSR_BINNING_GLOBAL_RADIX 0
+#define GSR_BINNING_TILE_BUCKET 1
+int gsr_set_binning_mode(int mode);
+int gsr_get_binning_mode(void);
+
+/* Performance knobs that never change results: "blend_fwd_waves" / "blend_bwd_waves" in {1, 2, 4} = waves that
+ * cooperate on one 16x16 tile (each lane then owns 4 / waves pixels). */
+int gsr_set_tuning(const char *key, int value);
+
+/* present[i] = (view-space z of means3D[i]) > 0.2          (CR/rasterizer_impl.cu:54-66, CR/auxiliary.h:139-164) */
+int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                     uint8_t *present, gsr_stream_t stream);
+
+/* Forward rasterisation.  Argument meaning and order follow Rasterizer::forward (CR/rasterizer.h:32-56):
+ *   P Gaussians, D active SH degree, M SH coefficients per Gaussian (shs is [P][M][3]);
+ *   background[3]; means3D[P][3]; colors_precomp[P][3]; opacities[P]; scales[P][3]; rotations[P][4] (r,x,y,z);
+ *   cov3D_precomp[P][6]; viewmatrix/projmatrix[16] (row-vector convention); cam_pos[3];
+ *   out_color[3][H][W], out_depth[H][W], out_alpha[H][W] (alpha = sum of blending weights), radii[P] (may be null).
+ * Outputs must be zero-filled by the caller like the reference binding does (DGR/rasterize_points.cu:69-72);
+ * *host_num_rendered receives the number of (Gaussian, tile) instances (the reference's return value). */
+int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc,
+                          void *binning_user, gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M,
+                          const float *background, int width, int height, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                          const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                          float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                          int *radii, int debug, int *host_num_rendered, gsr_stream_t stream);
+
+/* Backward rasterisation, Rasterizer::backward (CR/rasterizer.h:58-89).  R = num_rendered of the forward call;
+ * geom/binning/image buffers are the ones the forward call filled.  All dL_d* outputs must be zero-filled
+ * (DGR/rasterize_points.cu:159-167): dL_dmean2D[P][3], dL_dconic[P][4], dL_dopacity[P], dL_dcolor[P][3],
+ * dL_dmean3D[P][3], dL_dcov3D[P][6], dL_dsh[P][M][3], dL_dscale[P][3], dL_drot[P][4].
+ * `alphas` is accepted and ignored like in the reference kernel (CR/backward.cu:410). */
+int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height,
+                           const float *means3D, const float *shs, const float *colors_precomp,
+                           const float *alphas, const float *scales, float scale_modifier, const float *rotations,
+                           const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                           const float *campos, float tan_fovx, float tan_fovy, const int *radii,
+                           char *geom_buffer, char *binning_buffer, char *image_buffer, const float *dL_dpix,
+                           const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
+                           float *dL_dsh, float *dL_dscale, float *dL_drot, int debug, gsr_stream_t stream);
+
+/* Introspection of the private scratch buffers, for the parity tests only (copies device -> device):
+ * what = one of GSR_Q_*; dst must hold the documented element count. */
+#define GSR_Q_DEPTHS 0        /* float[P]            geom  */
+#define GSR_Q_MEANS2D 1       /* float[P][2]         geom  */
+#define GSR_Q_CONIC_OPACITY 2 /* float[P][4]         geom  */
+#define GSR_Q_RGB 3           /* float[P][3]         geom  */
+#define GSR_Q_COV3D 4         /* float[P][6]         geom  (only valid if computed from scales/rotations) */
+#define GSR_Q_TILES_TOUCHED 5 /* uint32[P]           geom  */
+#define GSR_Q_POINT_OFFSETS 6 /* uint32[P]           geom  (inclusive scan) */
+#define GSR_Q_CLAMPED 7       /* uint8[P][3]         geom  */
+#define GSR_Q_POINT_LIST 8    /* uint32[R]           binning (sorted Gaussian ids) */
+#define GSR_Q_KEYS_SORTED 9   /* uint64[R]           binning (tile << 32 | depth bits) */
+#define GSR_Q_RANGES 10       /* uint32[tiles][2]    image */
+#define GSR_Q_FINAL_T 11      /* float[H][W]         image */
+#define GSR_Q_N_CONTRIB 12    /* uint32[H][W]        image */
+int gsr_query_state(int what, int P, int R, int width, int height, const char *geom_buffer,
+                    const char *binning_buffer, const char *image_buffer, void *dst, gsr_stream_t stream);
+
+/* simple-knn: mean_dists[i] = mean of the 3 smallest squared distances from points[i] to the other points
+ * (SK/simple_knn.cu:185-221).  workspace must hold gsr_dist2_workspace_bytes(P) bytes. */
+size_t gsr_dist2_workspace_bytes(int P);
+int gsr_dist2(int P, const float *points, float *mean_dists, char *workspace, size_t workspace_bytes,
+              gsr_stream_t stream);
+
+/* Stand-alone stable LSD radix sort of (key, value) pairs on key bits [0, end_bit), the replacement of
+ * cub::DeviceRadixSort::SortPairs at CR/rasterizer_impl.cu:305-310 (u64 keys) and SK/simple_knn.cu:213 (u32 keys).
+ * workspace: gsr_sort_workspace_bytes(n). Results land in keys_out / vals_out; inputs are preserved. */
+size_t gsr_sort_workspace_bytes(size_t n);
+int gsr_sort_pairs_u64(size_t n, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
+                       uint32_t *vals_out, int end_bit, char *workspace, size_t workspace_bytes,
+                       gsr_stream_t stream);
+int gsr_sort_pairs_u32(size_t n, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
+                       uint32_t *vals_out, int end_bit, char *workspace, size_t workspace_bytes,
+                       gsr_stream_t stream);
+
+/* SMPL linear-blend skinning of P canonical points (the per-point part of coarse_deform_c2source,
+ * scene/gaussian_model.py:776-872, batch size 1).
+ *   query[P][3], normals[P][3] (may be null); smpl_verts[V][3] = big-pose vertices searched for the nearest
+ *   vertex (k = 1, lowest index wins ties); weights[V][24]; lbs_offsets[P][24] or null
+ *   (softmax(log(w + 1e-9) + offset)); A_big / A_pose [24][16] joint transforms; off_big / off_shape / off_pose
+ *   [V][3] per-vertex offset tables (PoseOff(theta_big), ShapeOff(beta), PoseOff(theta, dR)); R[9], Th[3].
+ * Outputs (any may be null except world_pts): vert_ids int32[P], bweights[P][24], smpl_pts[P][3],
+ *   world_pts[P][3], transforms[P][9], translation[P][3], world_normals[P][3]. */
+int gsr_lbs_forward(int P, int V, const float *query, const float *normals, const float *smpl_verts,
+                    const float *weights, const float *lbs_offsets, const float *A_big, const float *A_pose,
+                    const float *off_big, const float *off_shape, const float *off_pose, const float *R,
+                    const float *Th, int *vert_ids, float *bweights, float *smpl_pts, float *world_pts,
+                    float *transforms, float *translation, float *world_normals, gsr_stream_t stream);
+
+/* Backward of gsr_lbs_forward w.r.t. query, normals, lbs_offsets, A_pose, off_pose (A_big/off_big/off_shape
+ * belong to the constant big pose / shape and get no gradient in the reference training loop).
+ * Incoming: dL_dworld_pts[P][3], dL_dtransforms[P][9], dL_dworld_normals[P][3] (each may be null = zero).
+ * Outgoing (zero-filled by the caller, accumulated into): dL_dquery[P][3], dL_dnormals[P][3] (or null),
+ *   dL_dlbs_offsets[P][24] (or null), dL_dA_pose[24][16], dL_doff_pose[V][3]. */
+int gsr_lbs_backward(int P, int V, const float *query, const float *normals, const int *vert_ids,
+                     const float *weights, const float *lbs_offsets, const float *A_big, const float *A_pose,
+                     const float *off_big, const float *off_shape, const float *off_pose, const float *R,
+                     const float *dL_dworld_pts, const float *dL_dtransforms, const float *dL_dworld_normals,
+                     float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
+                     float *dL_doff_pose, gsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_INCLUDED */

@@ -1,0 +1,84 @@
+"""ctypes binding of libgsr.so (the C ABI declared in include/gsr.h).
+
+There is NO fallback: if the HIP library is missing or does not load, importing this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+# every symbol include/gsr.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning",
+    "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
+    "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
+    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward",
+]
+
+GSR_OK = 0
+Q = dict(DEPTHS=0, MEANS2D=1, CONIC_OPACITY=2, RGB=3, COV3D=4, TILES_TOUCHED=5, POINT_OFFSETS=6, CLAMPED=7,
+         POINT_LIST=8, KEYS_SORTED=9, RANGES=10, FINAL_T=11, N_CONTRIB=12)
+BINNING_GLOBAL_RADIX, BINNING_TILE_BUCKET = 0, 1
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first (python -m mygauhuman_amd.build, or "
+            "__graft_entry__.build()).  There is no CPU/PyTorch fallback for the rasterizer.")
+    lib = C.CDLL(LIB_PATH)
+    vp, fp, ip, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t  # device pointers travel as integers
+    lib.gsr_version.restype = C.c_int
+    lib.gsr_target_arch.restype = C.c_char_p
+    lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_set_binning_mode.argtypes = [C.c_int]
+    lib.gsr_get_binning_mode.restype = C.c_int
+    lib.gsr_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.gsr_mark_visible.argtypes = [C.c_int, fp, fp, fp, vp, vp]
+    lib.gsr_rasterize_forward.argtypes = [
+        ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp,
+        C.c_float, fp, fp, fp, fp, fp, C.c_float, C.c_float, C.c_int, fp, fp, fp, ip, C.c_int, C.POINTER(C.c_int), vp]
+    lib.gsr_rasterize_backward.argtypes = [
+        C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp,
+        C.c_float, C.c_float, ip, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
+    lib.gsr_query_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.gsr_dist2_workspace_bytes.argtypes = [C.c_int]
+    lib.gsr_dist2_workspace_bytes.restype = sz
+    lib.gsr_dist2.argtypes = [C.c_int, fp, fp, vp, sz, vp]
+    lib.gsr_sort_workspace_bytes.argtypes = [sz]
+    lib.gsr_sort_workspace_bytes.restype = sz
+    lib.gsr_sort_pairs_u64.argtypes = [sz, vp, vp, vp, vp, C.c_int, vp, sz, vp]
+    lib.gsr_sort_pairs_u32.argtypes = [sz, vp, vp, vp, vp, C.c_int, vp, sz, vp]
+    lib.gsr_lbs_forward.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp]
+    lib.gsr_lbs_backward.argtypes = [C.c_int, C.c_int, fp, fp, ip] + [fp] * 8 + [fp] * 3 + [fp] * 5 + [vp]
+    for name in ("gsr_set_binning_mode", "gsr_set_tuning", "gsr_mark_visible", "gsr_rasterize_forward",
+                 "gsr_rasterize_backward", "gsr_query_state", "gsr_dist2", "gsr_sort_pairs_u64", "gsr_sort_pairs_u32",
+                 "gsr_lbs_forward", "gsr_lbs_backward"):
+        getattr(lib, name).restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != GSR_OK:
+        msg = lib.gsr_last_error()
+        raise GsrError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor, or None for an empty tensor (selects the other input mode, like the reference)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def set_tuning(key, value):
+    check(lib.gsr_set_tuning(key.encode(), int(value)), "gsr_set_tuning")

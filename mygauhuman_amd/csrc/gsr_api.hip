@@ -1,0 +1,422 @@
+// gsr_api.hip -- the extern "C" surface of libgsr.so (declared in include/gsr.h) and the host-side
+// orchestration of the rasterizer (replaces CudaRasterizer::Rasterizer::forward/backward/markVisible,
+// CR/rasterizer_impl.cu:141-447).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "gsr_common.h"
+
+namespace gsr {
+
+static thread_local std::string g_error;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+int check_hip(hipError_t e, const char *what, const char *file, int line) {
+  if (e == hipSuccess) return GSR_OK;
+  set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return GSR_EHIP;
+}
+
+// CR/rasterizer_impl.cu:35-50
+static uint32_t higher_msb(uint32_t n) {
+  uint32_t msb = sizeof(n) * 4, step = msb;
+  while (step > 1) {
+    step /= 2;
+    if (n >> msb)
+      msb += step;
+    else
+      msb -= step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}
+
+static int g_binning_mode = GSR_BINNING_GLOBAL_RADIX;
+
+// pinned host word for the one device->host read of a forward call (num_rendered, CR/rasterizer_impl.cu:283)
+static int readback_u32(const uint32_t *dev, uint32_t *out, hipStream_t stream) {
+  static thread_local uint32_t *pinned = nullptr;
+  if (!pinned) GSR_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 64, hipHostMallocDefault));
+  GSR_HIP(hipMemcpyAsync(pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  GSR_HIP(hipStreamSynchronize(stream));
+  *out = *pinned;
+  return GSR_OK;
+}
+
+int set_blend_forward_waves(int nw);
+int set_blend_backward_waves(int nw);
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+int gsr_version(void) { return 100; }
+const char *gsr_target_arch(void) { return "gfx950"; }
+const char *gsr_last_error(void) { return g_error.c_str(); }
+
+int gsr_set_binning_mode(int mode) {
+  if (mode != GSR_BINNING_GLOBAL_RADIX && mode != GSR_BINNING_TILE_BUCKET) {
+    set_error("unknown binning mode %d", mode);
+    return GSR_EINVAL;
+  }
+  g_binning_mode = mode;
+  return GSR_OK;
+}
+int gsr_get_binning_mode(void) { return g_binning_mode; }
+
+int gsr_set_tuning(const char *key, int value) {
+  if (!key) return GSR_EINVAL;
+  if (!strcmp(key, "blend_fwd_waves")) return set_blend_forward_waves(value);
+  if (!strcmp(key, "blend_bwd_waves")) return set_blend_backward_waves(value);
+  set_error("unknown tuning key %s", key);
+  return GSR_EINVAL;
+}
+
+int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
+                     gsr_stream_t stream_) {
+  (void)projmatrix;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) {
+    set_error("gsr_mark_visible: bad arguments");
+    return GSR_EINVAL;
+  }
+  int rc = launch_mark_visible(P, means3D, viewmatrix, present, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
+int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
+                          gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
+                          int height, const float *means3D, const float *shs, const float *colors_precomp,
+                          const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+                          const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                          float tan_fovx, float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                          int *radii, int debug, int *host_num_rendered, gsr_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (host_num_rendered) *host_num_rendered = 0;
+  if (P < 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc || !host_num_rendered) {
+    set_error("gsr_rasterize_forward: bad sizes or missing allocation callbacks");
+    return GSR_EINVAL;
+  }
+  if (P == 0) return GSR_OK;  // DGR/rasterize_points.cu:84
+  if (!background || !means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_depth || !out_alpha) {
+    set_error("gsr_rasterize_forward: null required pointer");
+    return GSR_EINVAL;
+  }
+  if (!colors_precomp && !shs) {  // CR/rasterizer_impl.cu:244-247 (NUM_CHANNELS == 3 here, so SHs are acceptable)
+    set_error("gsr_rasterize_forward: provide SHs or precomputed colours");
+    return GSR_EINVAL;
+  }
+  if (!cov3D_precomp && (!scales || !rotations)) {
+    set_error("gsr_rasterize_forward: provide scales+rotations or a precomputed 3D covariance");
+    return GSR_EINVAL;
+  }
+  if (!colors_precomp && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) {
+    set_error("gsr_rasterize_forward: SH degree %d needs M >= %d coefficients (got %d)", D, (D + 1) * (D + 1), M);
+    return GSR_EINVAL;
+  }
+
+  const int grid_x = (width + TILE - 1) / TILE, grid_y = (height + TILE - 1) / TILE;
+  const size_t tiles = (size_t)grid_x * grid_y, npix = (size_t)width * height;
+
+  char *gchunk = geometry_alloc(geometry_user, geom_bytes((size_t)P));
+  if (!gchunk) {
+    set_error("geometry allocation callback returned null");
+    return GSR_ENOMEM;
+  }
+  GeomState geom = geom_from_chunk(gchunk, (size_t)P);
+  if (!radii) radii = geom.internal_radii;  // CR/rasterizer_impl.cu:231-234
+  char *ichunk = image_alloc(image_user, image_bytes(npix, tiles));
+  if (!ichunk) {
+    set_error("image allocation callback returned null");
+    return GSR_ENOMEM;
+  }
+  ImageState img = image_from_chunk(ichunk, npix, tiles);
+
+  PreprocessArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.P = P;
+  pa.D = D;
+  pa.M = M;
+  pa.means3D = means3D;
+  pa.scales = scales;
+  pa.rotations = rotations;
+  pa.opacities = opacities;
+  pa.shs = shs;
+  pa.cov3D_precomp = cov3D_precomp;
+  pa.colors_precomp = colors_precomp;
+  pa.scale_modifier = scale_modifier;
+  pa.view = viewmatrix;
+  pa.proj = projmatrix;
+  pa.campos = cam_pos;
+  pa.W = width;
+  pa.H = height;
+  pa.grid_x = grid_x;
+  pa.grid_y = grid_y;
+  pa.tan_fovx = tan_fovx;
+  pa.tan_fovy = tan_fovy;
+  pa.focal_y = height / (2.0f * tan_fovy);  // CR/rasterizer_impl.cu:224-225
+  pa.focal_x = width / (2.0f * tan_fovx);
+  pa.radii = radii;
+  pa.geom = geom;
+  pa.prefiltered = prefiltered;
+
+  int rc = launch_preprocess_forward(pa, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, debug);
+  rc = launch_scan_block_sums(geom, P, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, debug);
+
+  uint32_t R = 0;
+  rc = readback_u32(geom.total, &R, stream);
+  if (rc != GSR_OK) return rc;
+  *host_num_rendered = (int)R;
+
+  char *bchunk = binning_alloc(binning_user, binning_bytes((size_t)R));
+  if (!bchunk) {
+    set_error("binning allocation callback returned null");
+    return GSR_ENOMEM;
+  }
+  BinningState bin = binning_from_chunk(bchunk, (size_t)R);
+
+  if (g_binning_mode == GSR_BINNING_TILE_BUCKET) {
+    rc = bucket_binning(geom, radii, P, grid_x, grid_y, (size_t)R, bin, img.ranges, stream, debug);
+    if (rc != GSR_OK) return rc;
+  } else {
+    const int end_bit = 32 + (int)higher_msb((uint32_t)tiles);  // CR/rasterizer_impl.cu:302,310
+    const int passes = radix_passes(end_bit);
+    // duplicate into whichever buffer makes the last pass land in (keys_s, vals_s)
+    uint64_t *dup_k = (passes % 2) ? bin.keys_a : bin.keys_s;
+    uint32_t *dup_v = (passes % 2) ? bin.vals_a : bin.vals_s;
+    uint64_t *oth_k = (passes % 2) ? bin.keys_s : bin.keys_a;
+    uint32_t *oth_v = (passes % 2) ? bin.vals_s : bin.vals_a;
+    rc = launch_duplicate(geom, radii, P, grid_x, grid_y, dup_k, dup_v, stream);
+    if (rc != GSR_OK) return rc;
+    GSR_LAUNCH_CHECK(stream, debug);
+    rc = radix_sort_u64((size_t)R, dup_k, dup_v, oth_k, oth_v, dup_k, dup_v, end_bit, bin.hist, stream, debug);
+    if (rc != GSR_OK) return rc;
+    rc = launch_tile_ranges((size_t)R, bin.keys_s, img.ranges, tiles, stream);
+    if (rc != GSR_OK) return rc;
+    GSR_LAUNCH_CHECK(stream, debug);
+  }
+
+  BlendFwdArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.ranges = img.ranges;
+  fa.point_list = bin.vals_s;
+  fa.recs = geom.recs;
+  fa.W = width;
+  fa.H = height;
+  fa.grid_x = grid_x;
+  fa.grid_y = grid_y;
+  fa.bg = background;
+  fa.out_color = out_color;
+  fa.out_depth = out_depth;
+  fa.out_alpha = out_alpha;
+  fa.final_T = img.final_T;
+  fa.n_contrib = img.n_contrib;
+  rc = launch_blend_forward(fa, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, debug);
+  return GSR_OK;
+}
+
+int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+                           const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
+                           float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                           const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
+                           char *geom_buffer, char *binning_buffer, char *image_buffer, const float *dL_dpix,
+                           const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                           float *dL_dscale, float *dL_drot, int debug, gsr_stream_t stream_) {
+  (void)alphas;  // unused by the reference kernel as well (CR/backward.cu:410)
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (P < 0 || R < 0 || width <= 0 || height <= 0) {
+    set_error("gsr_rasterize_backward: bad sizes");
+    return GSR_EINVAL;
+  }
+  if (P == 0) return GSR_OK;
+  if (!geom_buffer || !binning_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !campos ||
+      !dL_dpix || !dL_ddepths || !dL_dalphas || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
+      !dL_dcov3D) {
+    set_error("gsr_rasterize_backward: null required pointer");
+    return GSR_EINVAL;
+  }
+  if ((shs && !dL_dsh) || (scales && (!rotations || !dL_dscale || !dL_drot))) {
+    set_error("gsr_rasterize_backward: missing gradient output for SH / scale / rotation inputs");
+    return GSR_EINVAL;
+  }
+  const int grid_x = (width + TILE - 1) / TILE, grid_y = (height + TILE - 1) / TILE;
+  const size_t tiles = (size_t)grid_x * grid_y, npix = (size_t)width * height;
+  GeomState geom = geom_from_chunk(geom_buffer, (size_t)P);
+  BinningState bin = binning_from_chunk(binning_buffer, (size_t)R);
+  ImageState img = image_from_chunk(image_buffer, npix, tiles);
+  if (!radii) radii = geom.internal_radii;
+
+  GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * GROW * sizeof(float), stream));
+  BlendBwdArgs ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.ranges = img.ranges;
+  ba.point_list = bin.vals_s;
+  ba.recs = geom.recs;
+  ba.W = width;
+  ba.H = height;
+  ba.grid_x = grid_x;
+  ba.grid_y = grid_y;
+  ba.bg = background;
+  ba.final_T = img.final_T;
+  ba.n_contrib = img.n_contrib;
+  ba.dL_dpix = dL_dpix;
+  ba.dL_ddepth = dL_ddepths;
+  ba.dL_dalpha = dL_dalphas;
+  ba.grad_rows = geom.grad_rows;
+  int rc = launch_blend_backward(ba, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, debug);
+
+  PreprocessBwdArgs pb;
+  memset(&pb, 0, sizeof(pb));
+  pb.P = P;
+  pb.D = D;
+  pb.M = M;
+  pb.means3D = means3D;
+  pb.shs = shs;
+  pb.scales = scales;
+  pb.rotations = rotations;
+  pb.cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;  // CR/rasterizer_impl.cu:424
+  pb.radii = radii;
+  pb.clamped = geom.clamped;
+  pb.scale_modifier = scale_modifier;
+  pb.view = viewmatrix;
+  pb.proj = projmatrix;
+  pb.campos = campos;
+  pb.W = width;
+  pb.H = height;
+  pb.tan_fovx = tan_fovx;
+  pb.tan_fovy = tan_fovy;
+  pb.focal_y = height / (2.0f * tan_fovy);
+  pb.focal_x = width / (2.0f * tan_fovx);
+  pb.grad_rows = geom.grad_rows;
+  pb.dL_dmean2D = dL_dmean2D;
+  pb.dL_dconic = dL_dconic;
+  pb.dL_dopacity = dL_dopacity;
+  pb.dL_dcolor = dL_dcolor;
+  pb.dL_dmean3D = dL_dmean3D;
+  pb.dL_dcov3D = dL_dcov3D;
+  pb.dL_dsh = dL_dsh;
+  pb.dL_dscale = dL_dscale;
+  pb.dL_drot = dL_drot;
+  rc = launch_preprocess_backward(pb, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, debug);
+  return GSR_OK;
+}
+
+int gsr_query_state(int what, int P, int R, int width, int height, const char *geom_buffer, const char *binning_buffer,
+                    const char *image_buffer, void *dst, gsr_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int grid_x = (width + TILE - 1) / TILE, grid_y = (height + TILE - 1) / TILE;
+  const size_t tiles = (size_t)grid_x * grid_y, npix = (size_t)width * height;
+  if (!dst) return GSR_EINVAL;
+  GeomState geom = geom_from_chunk(const_cast<char *>(geom_buffer), (size_t)P);
+  BinningState bin = binning_from_chunk(const_cast<char *>(binning_buffer), (size_t)R);
+  ImageState img = image_from_chunk(const_cast<char *>(image_buffer), npix, tiles);
+  const void *src = nullptr;
+  size_t bytes = 0;
+  switch (what) {
+    case GSR_Q_DEPTHS:
+    case GSR_Q_MEANS2D:
+    case GSR_Q_CONIC_OPACITY:
+    case GSR_Q_RGB:
+    case GSR_Q_CLAMPED: {
+      if (!geom_buffer) return GSR_EINVAL;
+      int rc = launch_query_recs(what, P, geom, dst, stream);
+      if (rc != GSR_OK) return rc;
+      GSR_LAUNCH_CHECK(stream, 0);
+      return GSR_OK;
+    }
+    case GSR_Q_COV3D: src = geom.cov3D; bytes = (size_t)P * 6 * 4; break;
+    case GSR_Q_TILES_TOUCHED: src = geom.tiles_touched; bytes = (size_t)P * 4; break;
+    case GSR_Q_POINT_OFFSETS: src = geom.point_offsets; bytes = (size_t)P * 4; break;
+    case GSR_Q_POINT_LIST: src = bin.vals_s; bytes = (size_t)R * 4; break;
+    case GSR_Q_KEYS_SORTED: src = bin.keys_s; bytes = (size_t)R * 8; break;
+    case GSR_Q_RANGES: src = img.ranges; bytes = tiles * 8; break;
+    case GSR_Q_FINAL_T: src = img.final_T; bytes = npix * 4; break;
+    case GSR_Q_N_CONTRIB: src = img.n_contrib; bytes = npix * 4; break;
+    default: set_error("gsr_query_state: unknown selector %d", what); return GSR_EINVAL;
+  }
+  if (bytes) GSR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+  return GSR_OK;
+}
+
+size_t gsr_sort_workspace_bytes(size_t n) {
+  size_t m = n ? n : 1;
+  return align_up(m * 8, 256) + align_up(m * 4, 256) + align_up(sort_hist_words(m) * 4, 256) + 1024;
+}
+
+static int sort_ws(size_t n, size_t key_bytes, char *ws, size_t ws_bytes, void **tk, uint32_t **tv, uint32_t **hist) {
+  if (!ws || ws_bytes < gsr_sort_workspace_bytes(n)) {
+    set_error("sort workspace too small (%zu < %zu)", ws_bytes, gsr_sort_workspace_bytes(n));
+    return GSR_ENOMEM;
+  }
+  size_t m = n ? n : 1;
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<size_t>(ws), 256));
+  *tk = p;
+  p += align_up(m * key_bytes, 256);
+  *tv = reinterpret_cast<uint32_t *>(p);
+  p += align_up(m * 4, 256);
+  *hist = reinterpret_cast<uint32_t *>(p);
+  return GSR_OK;
+}
+
+int gsr_sort_pairs_u64(size_t n, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                       int end_bit, char *workspace, size_t workspace_bytes, gsr_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (end_bit <= 0 || end_bit > 64 || (n && (!keys_in || !keys_out || !vals_in || !vals_out))) {
+    set_error("gsr_sort_pairs_u64: bad arguments");
+    return GSR_EINVAL;
+  }
+  void *tk;
+  uint32_t *tv, *hist;
+  int rc = sort_ws(n, 8, workspace, workspace_bytes, &tk, &tv, &hist);
+  if (rc != GSR_OK) return rc;
+  const int passes = radix_passes(end_bit);
+  uint64_t *t = reinterpret_cast<uint64_t *>(tk);
+  if (passes % 2)  // result lands in x
+    return radix_sort_u64(n, keys_in, vals_in, keys_out, vals_out, t, tv, end_bit, hist, stream, 0);
+  return radix_sort_u64(n, keys_in, vals_in, t, tv, keys_out, vals_out, end_bit, hist, stream, 0);
+}
+
+int gsr_sort_pairs_u32(size_t n, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                       int end_bit, char *workspace, size_t workspace_bytes, gsr_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (end_bit <= 0 || end_bit > 32 || (n && (!keys_in || !keys_out || !vals_in || !vals_out))) {
+    set_error("gsr_sort_pairs_u32: bad arguments");
+    return GSR_EINVAL;
+  }
+  void *tk;
+  uint32_t *tv, *hist;
+  int rc = sort_ws(n, 8, workspace, workspace_bytes, &tk, &tv, &hist);
+  if (rc != GSR_OK) return rc;
+  const int passes = radix_passes(end_bit);
+  uint32_t *t = reinterpret_cast<uint32_t *>(tk);
+  if (passes % 2) return radix_sort_u32(n, keys_in, vals_in, keys_out, vals_out, t, tv, end_bit, hist, stream, 0);
+  return radix_sort_u32(n, keys_in, vals_in, t, tv, keys_out, vals_out, end_bit, hist, stream, 0);
+}
+
+}  // extern "C"

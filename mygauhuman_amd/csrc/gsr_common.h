@@ -1,0 +1,240 @@
+// gsr_common.h -- shared declarations of libgsr.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/gsr.h"
+
+namespace gsr {
+
+constexpr int TILE = 16;        // CR/config.h:16-17
+constexpr int WAVE = 64;
+constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess / duplicate block (they share the block-local scan)
+
+// One 48-byte record per Gaussian: everything the blend kernels gather for a (Gaussian, tile) instance,
+// contiguous so that an instance costs one 48-B gather instead of four (CR/forward.cu:322-325,360-362 read
+// point_list -> means2D, conic_opacity, features, depths from four arrays).
+struct alignas(16) SplatRec {
+  float x, y, conic_a, conic_b;        // pixel centre, conic.x, conic.y
+  float conic_c, opacity, depth, r;    // conic.z (CUDA float3 .z), opacity, view depth, red
+  float g, b, pad0, pad1;
+};
+static_assert(sizeof(SplatRec) == 48, "SplatRec layout");
+
+// Packed per-Gaussian gradient row written by the blend backward (one 64-B line per Gaussian so that a
+// Gaussian's nine float atomics are one memory-side request): see blend_bwd.hip.
+constexpr int GROW = 16;  // floats per row: [0]=dmean2D.x [1]=dmean2D.y [2..4]=dconic.x,.y,.w [5]=dopacity [6..8]=dcolor
+
+struct GeomState {  // per Gaussian
+  SplatRec *recs;
+  float *cov3D;             // [P][6]
+  uint8_t *clamped;         // [P] bit c = colour channel c was clamped at 0
+  uint32_t *tiles_touched;  // [P]
+  uint32_t *point_offsets;  // [P] inclusive scan
+  int *internal_radii;      // [P]
+  uint32_t *block_incl;     // [P] block-local inclusive scan of tiles_touched
+  uint32_t *block_sums;     // [nblk]
+  uint32_t *block_prefix;   // [nblk] exclusive prefix of block_sums
+  uint32_t *total;          // [1] R
+  float *grad_rows;         // [P][GROW] backward accumulation rows (zeroed by the backward)
+};
+struct BinningState {  // per instance
+  uint64_t *keys_a;  // "unsorted" role
+  uint32_t *vals_a;
+  uint64_t *keys_s;  // sorted keys (final)
+  uint32_t *vals_s;  // point_list (final)
+  uint32_t *hist;    // radix histograms
+};
+struct ImageState {
+  float *final_T;       // [H*W]
+  uint32_t *n_contrib;  // [H*W]
+  uint2 *ranges;        // [tiles]
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+template <typename T>
+inline void carve(char *&p, T *&out, size_t count) {
+  p = reinterpret_cast<char *>(align_up(reinterpret_cast<size_t>(p), 256));
+  out = reinterpret_cast<T *>(p);
+  p += count * sizeof(T);
+}
+
+inline int pre_blocks(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
+constexpr int SORT_ITEMS = 16;                        // keys per thread in the radix passes
+constexpr int SORT_BLOCK = 256;                       // threads
+constexpr int SORT_TILE = SORT_ITEMS * SORT_BLOCK;    // keys per block
+inline size_t sort_blocks(size_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+inline size_t sort_hist_words(size_t n) { return 256 * (sort_blocks(n) ? sort_blocks(n) : 1) + 256; }
+
+inline GeomState geom_from_chunk(char *chunk, size_t P) {
+  GeomState g;
+  size_t nb = (size_t)pre_blocks((int)P);
+  carve(chunk, g.recs, P);
+  carve(chunk, g.cov3D, P * 6);
+  carve(chunk, g.clamped, P);
+  carve(chunk, g.tiles_touched, P);
+  carve(chunk, g.point_offsets, P);
+  carve(chunk, g.internal_radii, P);
+  carve(chunk, g.block_incl, P);
+  carve(chunk, g.block_sums, nb);
+  carve(chunk, g.block_prefix, nb);
+  carve(chunk, g.total, 4);
+  carve(chunk, g.grad_rows, P * GROW);
+  return g;
+}
+inline size_t geom_bytes(size_t P) {
+  GeomState g = geom_from_chunk(nullptr, P);
+  return reinterpret_cast<size_t>(g.grad_rows + P * GROW) + 256;
+}
+inline BinningState binning_from_chunk(char *chunk, size_t R) {
+  BinningState b;
+  size_t n = R ? R : 1;
+  carve(chunk, b.keys_a, n);
+  carve(chunk, b.vals_a, n);
+  carve(chunk, b.keys_s, n);
+  carve(chunk, b.vals_s, n);
+  carve(chunk, b.hist, sort_hist_words(n));
+  return b;
+}
+inline size_t binning_bytes(size_t R) {
+  BinningState b = binning_from_chunk(nullptr, R);
+  return reinterpret_cast<size_t>(b.hist + sort_hist_words(R ? R : 1)) + 256;
+}
+inline ImageState image_from_chunk(char *chunk, size_t npix, size_t tiles) {
+  ImageState s;
+  carve(chunk, s.final_T, npix);
+  carve(chunk, s.n_contrib, npix);
+  carve(chunk, s.ranges, tiles);
+  return s;
+}
+inline size_t image_bytes(size_t npix, size_t tiles) {
+  ImageState s = image_from_chunk(nullptr, npix, tiles);
+  return reinterpret_cast<size_t>(s.ranges + tiles) + 256;
+}
+
+// ---- error plumbing (gsr_api.hip) -------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what, const char *file, int line);
+#define GSR_HIP(expr)                                                        \
+  do {                                                                       \
+    int _rc = ::gsr::check_hip((expr), #expr, __FILE__, __LINE__);           \
+    if (_rc != GSR_OK) return _rc;                                           \
+  } while (0)
+// after a kernel launch: always collect launch errors; in debug mode also synchronise (CR/auxiliary.h:166-173)
+#define GSR_LAUNCH_CHECK(stream, debug)                                      \
+  do {                                                                       \
+    GSR_HIP(hipGetLastError());                                              \
+    if (debug) GSR_HIP(hipStreamSynchronize(stream));                        \
+  } while (0)
+
+// ---- kernel launchers (one translation unit each) ---------------------------------------------
+struct PreprocessArgs {
+  int P, D, M;
+  const float *means3D, *scales, *rotations, *opacities, *shs, *cov3D_precomp, *colors_precomp;
+  float scale_modifier;
+  const float *view, *proj, *campos;  // device pointers, read with scalar loads (wave-uniform)
+  int W, H, grid_x, grid_y;
+  float tan_fovx, tan_fovy, focal_x, focal_y;
+  int *radii;
+  GeomState geom;
+  int prefiltered;
+};
+int launch_preprocess_forward(const PreprocessArgs &a, hipStream_t stream);
+int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t stream);
+int launch_scan_block_sums(const GeomState &g, int P, hipStream_t stream);
+int launch_duplicate(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, uint64_t *keys,
+                     uint32_t *vals, hipStream_t stream);
+// generic stable LSD radix sort: pass 0 reads in_*, writes x_*; then ping-pongs x <-> y. Result is in x if the
+// number of passes is odd, else in y.  Returns the number of passes through *passes_out.
+int radix_sort_u64(size_t n, const uint64_t *in_k, const uint32_t *in_v, uint64_t *x_k, uint32_t *x_v, uint64_t *y_k,
+                   uint32_t *y_v, int end_bit, uint32_t *hist, hipStream_t stream, int debug);
+int radix_sort_u32(size_t n, const uint32_t *in_k, const uint32_t *in_v, uint32_t *x_k, uint32_t *x_v, uint32_t *y_k,
+                   uint32_t *y_v, int end_bit, uint32_t *hist, hipStream_t stream, int debug);
+inline int radix_passes(int end_bit) { return (end_bit + 7) / 8; }
+int launch_tile_ranges(size_t R, const uint64_t *keys_sorted, uint2 *ranges, size_t tiles, hipStream_t stream);
+
+struct BlendFwdArgs {
+  const uint2 *ranges;
+  const uint32_t *point_list;
+  const SplatRec *recs;
+  int W, H, grid_x, grid_y;
+  const float *bg;  // device pointer [3]
+  float *out_color, *out_depth, *out_alpha, *final_T;
+  uint32_t *n_contrib;
+};
+int launch_blend_forward(const BlendFwdArgs &a, hipStream_t stream);
+
+struct BlendBwdArgs {
+  const uint2 *ranges;
+  const uint32_t *point_list;
+  const SplatRec *recs;
+  int W, H, grid_x, grid_y;
+  const float *bg;  // device pointer [3]
+  const float *final_T;
+  const uint32_t *n_contrib;
+  const float *dL_dpix, *dL_ddepth, *dL_dalpha;
+  float *grad_rows;  // [P][GROW], zeroed
+};
+int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream);
+
+struct PreprocessBwdArgs {
+  int P, D, M;
+  const float *means3D, *shs, *scales, *rotations, *cov3D;  // cov3D = precomputed or geom.cov3D
+  const int *radii;
+  const uint8_t *clamped;
+  float scale_modifier;
+  const float *view, *proj, *campos;
+  int W, H;
+  float tan_fovx, tan_fovy, focal_x, focal_y;
+  const float *grad_rows;
+  float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+};
+int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream);
+
+int launch_query_recs(int what, int P, const GeomState &g, void *dst, hipStream_t stream);
+
+// tile-bucket binning (binning_bucket.hip)
+int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t R, BinningState &b,
+                   uint2 *ranges, hipStream_t stream, int debug);
+
+}  // namespace gsr
+
+// ---- device helpers -----------------------------------------------------------------------------
+#if defined(__HIPCC__)
+namespace gsr {
+
+// float -> int like v_cvt_i32_f32 / cvt.rzi.s32.f32: truncate, saturate, NaN -> 0 (explicit so the oracle and the
+// kernels agree for any input).
+__device__ __forceinline__ int f2i_sat(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)f;
+}
+
+// CR/auxiliary.h:46-56
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int &x0, int &y0, int &x1,
+                                          int &y1) {
+  const float r = (float)radius;
+  x0 = min(gx, max(0, f2i_sat((px - r) / (float)TILE)));
+  y0 = min(gy, max(0, f2i_sat((py - r) / (float)TILE)));
+  x1 = min(gx, max(0, f2i_sat((px + r + (float)(TILE - 1)) / (float)TILE)));
+  y1 = min(gy, max(0, f2i_sat((py + r + (float)(TILE - 1)) / (float)TILE)));
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// wave64 inclusive scan (uint32 add) with shuffles
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    uint32_t o = __shfl_up(v, d, WAVE);
+    if (lane >= (uint32_t)d) v += o;
+  }
+  return v;
+}
+
+}  // namespace gsr
+#endif

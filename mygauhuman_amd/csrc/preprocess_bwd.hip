@@ -1,0 +1,265 @@
+// preprocess_bwd.hip -- per-Gaussian backward: conic -> cov2D -> (cov3D, mean), projection, SH, scale/rotation.
+// One fused kernel replaces computeCov2DCUDA (CR/backward.cu:144-274) + preprocessCUDA (:346-396) and also
+// unpacks the blend kernel's packed gradient rows into the binding's dL_dmean2D / dL_dconic / dL_dopacity /
+// dL_dcolor tensors (DGR/rasterize_points.cu:159-167,206).  GLM products are written out in GLM's column-major
+// evaluation order, m[c][r] = column c, row r.
+#include "gsr_common.h"
+
+namespace gsr {
+
+__constant__ float bSH0 = 0.28209479177387814f;  // CR/auxiliary.h:22-39
+__constant__ float bSH1 = 0.4886025119029199f;
+__constant__ float bSH2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                              0.5462742152960396f};
+__constant__ float bSH3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                              -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+
+// CR/backward.cu:20-139
+__device__ __forceinline__ void sh_backward(int deg, const float3 pos, const float *campos, const float *sh,
+                                            uint32_t clamp_bits, const float3 dL_dcolor, float *dL_dmean, float *dL_dsh) {
+  const float d0x = pos.x - campos[0], d0y = pos.y - campos[1], d0z = pos.z - campos[2];
+  const float len = sqrtf(d0x * d0x + d0y * d0y + d0z * d0z);
+  const float x = d0x / len, y = d0y / len, z = d0z / len;
+  const float dRGB[3] = {(clamp_bits & 1u) ? 0.f : dL_dcolor.x, (clamp_bits & 2u) ? 0.f : dL_dcolor.y,
+                         (clamp_bits & 4u) ? 0.f : dL_dcolor.z};
+  float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
+#define S(k, ch) sh[(k) * 3 + (ch)]
+#define OUT(k, w)                     \
+  {                                   \
+    const float _w = (w);             \
+    dL_dsh[(k) * 3 + 0] = _w * dRGB[0]; \
+    dL_dsh[(k) * 3 + 1] = _w * dRGB[1]; \
+    dL_dsh[(k) * 3 + 2] = _w * dRGB[2]; \
+  }
+  OUT(0, bSH0);
+  if (deg > 0) {
+    OUT(1, -bSH1 * y);
+    OUT(2, bSH1 * z);
+    OUT(3, -bSH1 * x);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      ddx[ch] = -bSH1 * S(3, ch);
+      ddy[ch] = -bSH1 * S(1, ch);
+      ddz[ch] = bSH1 * S(2, ch);
+    }
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      OUT(4, bSH2[0] * xy);
+      OUT(5, bSH2[1] * yz);
+      OUT(6, bSH2[2] * (2.f * zz - xx - yy));
+      OUT(7, bSH2[3] * xz);
+      OUT(8, bSH2[4] * (xx - yy));
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) {
+        ddx[ch] += bSH2[0] * y * S(4, ch) + bSH2[2] * 2.f * -x * S(6, ch) + bSH2[3] * z * S(7, ch) + bSH2[4] * 2.f * x * S(8, ch);
+        ddy[ch] += bSH2[0] * x * S(4, ch) + bSH2[1] * z * S(5, ch) + bSH2[2] * 2.f * -y * S(6, ch) + bSH2[4] * 2.f * -y * S(8, ch);
+        ddz[ch] += bSH2[1] * y * S(5, ch) + bSH2[2] * 2.f * 2.f * z * S(6, ch) + bSH2[3] * x * S(7, ch);
+      }
+      if (deg > 2) {
+        OUT(9, bSH3[0] * y * (3.f * xx - yy));
+        OUT(10, bSH3[1] * xy * z);
+        OUT(11, bSH3[2] * y * (4.f * zz - xx - yy));
+        OUT(12, bSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+        OUT(13, bSH3[4] * x * (4.f * zz - xx - yy));
+        OUT(14, bSH3[5] * z * (xx - yy));
+        OUT(15, bSH3[6] * x * (xx - 3.f * yy));
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          ddx[ch] += (bSH3[0] * S(9, ch) * 3.f * 2.f * xy + bSH3[1] * S(10, ch) * yz + bSH3[2] * S(11, ch) * -2.f * xy +
+                      bSH3[3] * S(12, ch) * -3.f * 2.f * xz + bSH3[4] * S(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                      bSH3[5] * S(14, ch) * 2.f * xz + bSH3[6] * S(15, ch) * 3.f * (xx - yy));
+          ddy[ch] += (bSH3[0] * S(9, ch) * 3.f * (xx - yy) + bSH3[1] * S(10, ch) * xz +
+                      bSH3[2] * S(11, ch) * (-3.f * yy + 4.f * zz - xx) + bSH3[3] * S(12, ch) * -3.f * 2.f * yz +
+                      bSH3[4] * S(13, ch) * -2.f * xy + bSH3[5] * S(14, ch) * -2.f * yz + bSH3[6] * S(15, ch) * -3.f * 2.f * xy);
+          ddz[ch] += (bSH3[1] * S(10, ch) * xy + bSH3[2] * S(11, ch) * 4.f * 2.f * yz +
+                      bSH3[3] * S(12, ch) * 3.f * (2.f * zz - xx - yy) + bSH3[4] * S(13, ch) * 4.f * 2.f * xz +
+                      bSH3[5] * S(14, ch) * (xx - yy));
+        }
+      }
+    }
+  }
+#undef S
+#undef OUT
+  const float dd0 = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
+  const float dd1 = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
+  const float dd2 = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
+  // dnormvdv, CR/auxiliary.h:107-117
+  const float sum2 = d0x * d0x + d0y * d0y + d0z * d0z;
+  const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+  dL_dmean[0] += ((+sum2 - d0x * d0x) * dd0 - d0y * d0x * dd1 - d0z * d0x * dd2) * inv32;
+  dL_dmean[1] += (-d0x * d0y * dd0 + (sum2 - d0y * d0y) * dd1 - d0z * d0y * dd2) * inv32;
+  dL_dmean[2] += (-d0x * d0z * dd0 - d0y * d0z * dd1 + (sum2 - d0z * d0z) * dd2) * inv32;
+}
+
+// CR/backward.cu:278-341 (quaternion used as given, no normalisation Jacobian)
+__device__ __forceinline__ void cov3d_backward(const float3 sc, float mod, const float4 q, const float *d, float *dL_dscale,
+                                               float *dL_drot) {
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  float R[3][3];
+  R[0][0] = 1.f - 2.f * (y * y + z * z);
+  R[0][1] = 2.f * (x * y - r * z);
+  R[0][2] = 2.f * (x * z + r * y);
+  R[1][0] = 2.f * (x * y + r * z);
+  R[1][1] = 1.f - 2.f * (x * x + z * z);
+  R[1][2] = 2.f * (y * z - r * x);
+  R[2][0] = 2.f * (x * z - r * y);
+  R[2][1] = 2.f * (y * z + r * x);
+  R[2][2] = 1.f - 2.f * (x * x + y * y);
+  const float s[3] = {mod * sc.x, mod * sc.y, mod * sc.z};
+  float M[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) M[c][rr] = s[rr] * R[c][rr];
+  const float dS[3][3] = {{d[0], 0.5f * d[1], 0.5f * d[2]}, {0.5f * d[1], d[3], 0.5f * d[4]}, {0.5f * d[2], 0.5f * d[4], d[5]}};
+  float dMt[3][3];  // dMt[c][r] = dL_dM[r][c], dL_dM = (2 M) dL_dSigma
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++)
+      dMt[rr][c] = (2.0f * M[0][rr]) * dS[c][0] + (2.0f * M[1][rr]) * dS[c][1] + (2.0f * M[2][rr]) * dS[c][2];
+#pragma unroll
+  for (int k = 0; k < 3; k++) dL_dscale[k] = R[0][k] * dMt[k][0] + R[1][k] * dMt[k][1] + R[2][k] * dMt[k][2];
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) dMt[k][rr] *= s[k];
+  dL_drot[0] = 2 * z * (dMt[0][1] - dMt[1][0]) + 2 * y * (dMt[2][0] - dMt[0][2]) + 2 * x * (dMt[1][2] - dMt[2][1]);
+  dL_drot[1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] - dMt[2][1]) -
+               4 * x * (dMt[2][2] + dMt[1][1]);
+  dL_drot[2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] - dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) -
+               4 * y * (dMt[2][2] + dMt[0][0]);
+  dL_drot[3] = 2 * r * (dMt[0][1] - dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) -
+               4 * z * (dMt[1][1] + dMt[0][0]);
+}
+
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBwdArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.P || !(a.radii[i] > 0)) return;
+  const float4 *row = reinterpret_cast<const float4 *>(a.grad_rows + (size_t)i * GROW);
+  const float4 g0 = row[0], g1 = row[1], g2 = row[2];
+  // unpack the blend gradients into the binding's tensors
+  a.dL_dmean2D[3 * (size_t)i + 0] = g0.x;
+  a.dL_dmean2D[3 * (size_t)i + 1] = g0.y;
+  a.dL_dconic[4 * (size_t)i + 0] = g0.z;
+  a.dL_dconic[4 * (size_t)i + 1] = g0.w;
+  a.dL_dconic[4 * (size_t)i + 3] = g1.x;
+  a.dL_dopacity[i] = g1.y;
+  a.dL_dcolor[3 * (size_t)i + 0] = g1.z;
+  a.dL_dcolor[3 * (size_t)i + 1] = g1.w;
+  a.dL_dcolor[3 * (size_t)i + 2] = g2.x;
+  const float dcx = g0.z, dcy = g0.w, dcz = g1.x;
+
+  const float *vm = a.view, *proj = a.proj;
+  const float3 mean = make_float3(a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]);
+  float c6[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) c6[k] = a.cov3D[6 * (size_t)i + k];
+
+  // ---- computeCov2DCUDA ----
+  float3 t = make_float3(vm[0] * mean.x + vm[4] * mean.y + vm[8] * mean.z + vm[12],
+                         vm[1] * mean.x + vm[5] * mean.y + vm[9] * mean.z + vm[13],
+                         vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14]);
+  const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+  const float txtz = t.x / t.z, tytz = t.y / t.z;
+  t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+  t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+  const float gxm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  const float gym = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  const float h_x = a.focal_x, h_y = a.focal_y;
+  const float J00 = h_x / t.z, J02 = -(h_x * t.x) / (t.z * t.z), J11 = h_y / t.z, J12 = -(h_y * t.y) / (t.z * t.z);
+  const float Wm[3][3] = {{vm[0], vm[4], vm[8]}, {vm[1], vm[5], vm[9]}, {vm[2], vm[6], vm[10]}};
+  float T[2][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    T[0][r] = Wm[0][r] * J00 + Wm[2][r] * J02;
+    T[1][r] = Wm[1][r] * J11 + Wm[2][r] * J12;
+  }
+  const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  float A[3][2];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    A[c][0] = T[0][0] * V[c][0] + T[0][1] * V[c][1] + T[0][2] * V[c][2];
+    A[c][1] = T[1][0] * V[c][0] + T[1][1] * V[c][1] + T[1][2] * V[c][2];
+  }
+  const float ca = (A[0][0] * T[0][0] + A[1][0] * T[0][1] + A[2][0] * T[0][2]) + 0.3f;
+  const float cb = A[0][1] * T[0][0] + A[1][1] * T[0][1] + A[2][1] * T[0][2];
+  const float cc = (A[0][1] * T[1][0] + A[1][1] * T[1][1] + A[2][1] * T[1][2]) + 0.3f;
+  const float denom = ca * cc - cb * cb;
+  float dL_da = 0, dL_db = 0, dL_dc = 0;
+  const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+  float dcov[6];
+  if (denom2inv != 0) {
+    dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+    dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+    dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+    dcov[0] = (T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc);
+    dcov[3] = (T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc);
+    dcov[5] = (T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc);
+    dcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][1] * dL_dc;
+    dcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2 * T[1][0] * T[1][2] * dL_dc;
+    dcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2 * T[1][1] * T[1][2] * dL_dc;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) dcov[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+  float dT[2][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float tv0 = T[0][0] * V[k][0] + T[0][1] * V[k][1] + T[0][2] * V[k][2];
+    const float tv1 = T[1][0] * V[k][0] + T[1][1] * V[k][1] + T[1][2] * V[k][2];
+    dT[0][k] = 2 * tv0 * dL_da + tv1 * dL_db;
+    dT[1][k] = 2 * tv1 * dL_dc + tv0 * dL_db;
+  }
+  const float dJ00 = Wm[0][0] * dT[0][0] + Wm[0][1] * dT[0][1] + Wm[0][2] * dT[0][2];
+  const float dJ02 = Wm[2][0] * dT[0][0] + Wm[2][1] * dT[0][1] + Wm[2][2] * dT[0][2];
+  const float dJ11 = Wm[1][0] * dT[1][0] + Wm[1][1] * dT[1][1] + Wm[1][2] * dT[1][2];
+  const float dJ12 = Wm[2][0] * dT[1][0] + Wm[2][1] * dT[1][1] + Wm[2][2] * dT[1][2];
+  const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+  const float dtx = gxm * -h_x * tz2 * dJ02;
+  const float dty = gym * -h_y * tz2 * dJ12;
+  const float dtz = -h_x * tz2 * dJ00 - h_y * tz2 * dJ11 + (2 * h_x * t.x) * tz3 * dJ02 + (2 * h_y * t.y) * tz3 * dJ12;
+  float dm[3];
+  dm[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
+  dm[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+  dm[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+
+  // ---- preprocessCUDA: projection term ----
+  const float mhw = proj[3] * mean.x + proj[7] * mean.y + proj[11] * mean.z + proj[15];
+  const float m_w = 1.0f / (mhw + 0.0000001f);
+  const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+  const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+  const float g2x = g0.x, g2y = g0.y;
+  dm[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+  dm[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+  dm[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+
+  if (a.shs)
+    sh_backward(a.D, mean, a.campos, a.shs + (size_t)i * a.M * 3, a.clamped[i], make_float3(g1.z, g1.w, g2.x), dm,
+                a.dL_dsh + (size_t)i * a.M * 3);
+  a.dL_dmean3D[3 * (size_t)i + 0] = dm[0];
+  a.dL_dmean3D[3 * (size_t)i + 1] = dm[1];
+  a.dL_dmean3D[3 * (size_t)i + 2] = dm[2];
+
+  if (a.scales) {
+    float ds[3], dq[4];
+    const float3 sc = make_float3(a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2]);
+    const float4 q = make_float4(a.rotations[4 * (size_t)i], a.rotations[4 * (size_t)i + 1], a.rotations[4 * (size_t)i + 2],
+                                 a.rotations[4 * (size_t)i + 3]);
+    cov3d_backward(sc, a.scale_modifier, q, dcov, ds, dq);
+#pragma unroll
+    for (int k = 0; k < 3; k++) a.dL_dscale[3 * (size_t)i + k] = ds[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a.dL_drot[4 * (size_t)i + k] = dq[k];
+  }
+}
+
+int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream) {
+  if (a.P <= 0) return GSR_OK;
+  hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+  return GSR_OK;
+}
+
+}  // namespace gsr

@@ -1,0 +1,147 @@
+"""`diff_gaussian_rasterization._C`: the three raw bindings of the reference extension (DGR/ext.cpp:15-19),
+same positional signatures and return tuples (DGR/rasterize_points.h:19-70), implemented over the C ABI of
+libgsr.so.  Torch only owns memory and the stream here; all compute is in the HIP library."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import ALLOC_FN, check, lib, ptr
+
+
+def _f32c(t, name):
+    if t.numel() and t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t.contiguous()  # silent copy for non-contiguous inputs, DGR/rasterize_points.cu:97-116
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _Scratch:
+    """One growable byte tensor handed to the library through an allocation callback (the resize lambda of
+    DGR/rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.error = None
+        self.cb = ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        try:
+            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception as ex:  # noqa: BLE001 -- exceptions cannot cross the C boundary
+            self.error = ex
+            return 0
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """RasterizeGaussiansCUDA (DGR/rasterize_points.cu:36-120)."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("rasterize_gaussians: tensors must live on a HIP device (no CPU path)")
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+    out_alpha = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+    rendered = C.c_int(0)
+    if P != 0:
+        M = sh.size(1) if sh.numel() != 0 else 0
+        means3D, colors, opacity = _f32c(means3D, "means3D"), _f32c(colors, "colors"), _f32c(opacity, "opacity")
+        scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
+        sh, background = _f32c(sh, "sh"), _f32c(background, "background")
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
+        with torch.cuda.device(dev):
+            rc = lib.gsr_rasterize_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), ptr(background), W, H,
+                ptr(means3D), ptr(sh), ptr(colors), ptr(opacity), ptr(scales), float(scale_modifier), ptr(rotations),
+                ptr(cov3D_precomp), ptr(viewmatrix), ptr(projmatrix), ptr(campos), float(tan_fovx), float(tan_fovy),
+                int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
+                radii.data_ptr(), int(bool(debug)), C.byref(rendered), _stream(dev))
+        for s in (geom, binning, img):
+            if s.error is not None:
+                raise s.error
+        check(rc, "gsr_rasterize_forward")
+    return rendered.value, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                 dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,
+                                 debug):
+    """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207)."""
+    dev = means3D.device
+    P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    opts = dict(dtype=torch.float32, device=dev)
+    dL_dmeans3D = torch.zeros((P, 3), **opts)
+    dL_dmeans2D = torch.zeros((P, 3), **opts)
+    dL_dcolors = torch.zeros((P, 3), **opts)
+    dL_dconic = torch.zeros((P, 2, 2), **opts)
+    dL_dopacity = torch.zeros((P, 1), **opts)
+    dL_dcov3D = torch.zeros((P, 6), **opts)
+    dL_dsh = torch.zeros((P, M, 3), **opts)
+    dL_dscales = torch.zeros((P, 3), **opts)
+    dL_drotations = torch.zeros((P, 4), **opts)
+    if P != 0:
+        means3D, colors = _f32c(means3D, "means3D"), _f32c(colors, "colors")
+        scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
+        sh, background, alphas = _f32c(sh, "sh"), _f32c(background, "background"), _f32c(alphas, "alphas")
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
+        dL_dout_color, dL_dout_depth = _f32c(dL_dout_color, "dL_dout_color"), _f32c(dL_dout_depth, "dL_dout_depth")
+        dL_dout_alpha = _f32c(dL_dout_alpha, "dL_dout_alpha")
+        radii = radii.contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_rasterize_backward(
+                P, int(degree), int(M), int(R), ptr(background), W, H, ptr(means3D), ptr(sh), ptr(colors), ptr(alphas),
+                ptr(scales), float(scale_modifier), ptr(rotations), ptr(cov3D_precomp), ptr(viewmatrix), ptr(projmatrix),
+                ptr(campos), float(tan_fovx), float(tan_fovy), ptr(radii), geomBuffer.data_ptr(),
+                binningBuffer.data_ptr(), imageBuffer.data_ptr(), ptr(dL_dout_color), ptr(dL_dout_depth),
+                ptr(dL_dout_alpha), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
+                _stream(dev))
+        check(rc, "gsr_rasterize_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (DGR/rasterize_points.cu:209-228)."""
+    if not means3D.is_cuda:
+        raise RuntimeError("mark_visible: tensors must live on a HIP device (no CPU path)")
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        means3D, viewmatrix, projmatrix = _f32c(means3D, "means3D"), _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix")
+        with torch.cuda.device(means3D.device):
+            check(lib.gsr_mark_visible(P, ptr(means3D), ptr(viewmatrix), ptr(projmatrix), present.data_ptr(),
+                                       _stream(means3D.device)), "gsr_mark_visible")
+    return present
+
+
+def query_state(what, P, R, W, H, geomBuffer, binningBuffer, imageBuffer):
+    """Parity-test helper: copy one private scratch array out of the opaque buffers (gsr_query_state)."""
+    dev = geomBuffer.device
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    shapes = dict(DEPTHS=((P,), torch.float32), MEANS2D=((P, 2), torch.float32), CONIC_OPACITY=((P, 4), torch.float32),
+                  RGB=((P, 3), torch.float32), COV3D=((P, 6), torch.float32), TILES_TOUCHED=((P,), torch.int32),
+                  POINT_OFFSETS=((P,), torch.int32), CLAMPED=((P, 3), torch.uint8), POINT_LIST=((R,), torch.int32),
+                  KEYS_SORTED=((R,), torch.int64), RANGES=((tiles, 2), torch.int32), FINAL_T=((H, W), torch.float32),
+                  N_CONTRIB=((H, W), torch.int32))
+    shape, dt = shapes[what]
+    out = torch.zeros(shape, dtype=dt, device=dev)
+    if out.numel():
+        with torch.cuda.device(dev):
+            check(lib.gsr_query_state(_lib.Q[what], P, R, W, H, geomBuffer.data_ptr(),
+                                      binningBuffer.data_ptr() if binningBuffer.numel() else None,
+                                      imageBuffer.data_ptr(), out.data_ptr(), _stream(dev)), "gsr_query_state")
+    return out

@@ -1,0 +1,116 @@
+"""Operator API of the rasterizer -- same names, argument order, return values and error behaviour as the
+reference's `diff_gaussian_rasterization` package (DGR/diff_gaussian_rasterization/__init__.py:21-223), backed by
+the MI355X HIP library instead of the CUDA extension.
+
+    GaussianRasterizationSettings   (:160-172)  NamedTuple, 12 fields, same order
+    GaussianRasterizer              (:174-223)  nn.Module: forward(...) -> (color, radii, depth, alpha); markVisible
+    rasterize_gaussians             (:21-42)    functional form
+    _C                              (DGR/ext.cpp:15-19) raw bindings used by baking.py:259-282
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU copy of an argument tuple, taken before the call so a crash cannot corrupt it (:17-19)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_guarded(fn, args, debug, dump_name, phase):
+    """Run a raw binding; in debug mode dump the inputs to `dump_name` if it raises (:83-90, :135-142)."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print(f"\nAn error occured in {phase}. Please forward {dump_name} for debugging.")
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        # the binding's positional order (DGR/rasterize_points.h:19-39)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer, alpha)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer,
+         alpha) = ctx.saved_tensors
+        # DGR/rasterize_points.h:41-66
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh,
+                rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = _call_guarded(_C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+        # gradients in the order of forward()'s inputs (:146-156); raster_settings gets None
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points in front of the near plane of this camera (:179-188)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])  # CPU, zero elements -> null pointer -> the other input mode (:200-210)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

@@ -1,0 +1,79 @@
+"""GPU parity tests of the stand-alone radix sort and distCUDA2 (bit-exact: integer / exact-search work)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _sort(keys, vals, end_bit):
+    from mygauhuman_amd._lib import check, lib
+    n = keys.shape[0]
+    k64 = keys.dtype == np.uint64
+    dk = torch.from_numpy(keys.view(np.int64 if k64 else np.int32)).cuda()
+    dv = torch.from_numpy(vals.view(np.int32)).cuda()
+    ok, ov = torch.zeros_like(dk), torch.zeros_like(dv)
+    wsb = lib.gsr_sort_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    fn = lib.gsr_sort_pairs_u64 if k64 else lib.gsr_sort_pairs_u32
+    check(fn(n, dk.data_ptr() if n else None, ok.data_ptr() if n else None, dv.data_ptr() if n else None,
+             ov.data_ptr() if n else None, end_bit, ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream), "sort")
+    torch.cuda.synchronize()
+    assert torch.equal(dk.cpu(), torch.from_numpy(keys.view(np.int64 if k64 else np.int32)))  # inputs preserved
+    return ok.cpu().numpy().view(keys.dtype), ov.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 4095, 4096, 4097, 100001, 1 << 20])
+@pytest.mark.parametrize("kind", ["u64_45", "u64_43", "u64_64", "u32_32", "u32_30", "u32_few"])
+def test_sort_pairs_is_a_stable_sort(n, kind):
+    rng = np.random.default_rng(n + len(kind))
+    if kind.startswith("u64"):
+        end_bit = int(kind.split("_")[1])
+        keys = rng.integers(0, 1 << min(end_bit, 63), n, dtype=np.uint64)
+        if end_bit < 64:  # duplicates: depth bits of Gaussians that share a tile
+            keys[: n // 2] = keys[n // 2: n // 2 + n // 2] if n >= 2 else keys[: n // 2]
+    else:
+        end_bit = 32 if kind != "u32_30" else 30
+        hi = 16 if kind == "u32_few" else (1 << end_bit)
+        keys = rng.integers(0, hi, n, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    ok, ov = _sort(keys, vals, end_bit)
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(ok, keys[order])
+    np.testing.assert_array_equal(ov, vals[order])
+
+
+def test_sort_ignores_bits_above_end_bit():
+    rng = np.random.default_rng(0)
+    n = 50000
+    keys = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+    vals = np.arange(n, dtype=np.uint32)
+    ok, ov = _sort(keys, vals, 24)
+    order = np.argsort(keys & np.uint64((1 << 24) - 1), kind="stable")
+    np.testing.assert_array_equal(ov, vals[order])
+    np.testing.assert_array_equal(ok, keys[order])
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 700, 1024, 1025, 6890, 30000])
+def test_dist2_matches_oracle_bit_exact(oracle, P):
+    from mygauhuman_amd.simple_knn._C import distCUDA2
+    rng = np.random.default_rng(P)
+    pts = rng.normal(0, 1, (P, 3)).astype(np.float32) * np.array([0.9, 0.9, 0.15], np.float32)
+    if P >= 20:
+        pts[: P // 10] = pts[P // 10: 2 * (P // 10)]  # coincident points -> zero distances
+    got = distCUDA2(util.to_dev(pts)).cpu().numpy()
+    want = oracle.dist2_brute(pts)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_dist2_clustered_and_shifted(oracle):
+    """Clusters far from the origin (the AABB always contains the origin, SK/simple_knn.cu:191) + a degenerate axis."""
+    from mygauhuman_amd.simple_knn._C import distCUDA2
+    rng = np.random.default_rng(3)
+    centers = rng.uniform(5, 9, (12, 3))
+    pts = (centers[rng.integers(0, 12, 8000)] + rng.normal(0, 0.01, (8000, 3))).astype(np.float32)
+    pts[:, 2] = 7.0
+    got = distCUDA2(util.to_dev(pts)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.dist2_brute(pts))

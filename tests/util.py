@@ -1,0 +1,85 @@
+"""Shared helpers of the parity tests: seeded scenes, the HIP path through the raw `_C` bindings, the oracle path."""
+import numpy as np
+import torch
+
+from mygauhuman_amd import synthetic
+
+
+def make_scene(P, W, H, seed=0, deg=3, scale=0.02, behind_frac=0.0):
+    cam, g = synthetic.uniform_scene(P, W, H, seed=seed, sh_degree=deg, log_scale_mean=float(np.log(scale)))
+    rng = np.random.default_rng(seed + 77)
+    if behind_frac > 0 and P > 0:  # some Gaussians behind / too close to the camera -> culled
+        k = max(1, int(P * behind_frac))
+        g["means3D"][:k, 2] = rng.uniform(-1.0, 0.2, k).astype(np.float32)
+    A = rng.normal(0, scale, (P, 3, 3)).astype(np.float32)
+    g["cov3D"] = (np.stack([(a @ a.T + 1e-6 * np.eye(3, dtype=np.float32))[np.triu_indices(3)] for a in A]).astype(np.float32)
+                  if P else np.zeros((0, 6), np.float32))
+    return cam, g
+
+
+def oracle_forward(oracle, cam, g, bg, mode):
+    kw = dict(scale_modifier=1.0)
+    if mode == "sh":
+        kw.update(scales=g["scales"], rotations=g["rotations"], shs=g["shs"], degree=g["sh_degree"])
+    else:
+        kw.update(cov3D_precomp=g["cov3D"], colors_precomp=g["colors"])
+    return oracle.rasterize_forward(g["means3D"], g["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"],
+                                    cam["W"], cam["H"], cam["tanfovx"], cam["tanfovy"], bg, **kw)
+
+
+def to_dev(a, dev="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def hip_forward(cam, g, bg, mode, debug=False, dev="cuda"):
+    """Forward through the raw binding (same 19 positional args as the reference's _C.rasterize_gaussians)."""
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    e = torch.empty(0)
+    t = {k: to_dev(v, dev) for k, v in g.items() if isinstance(v, np.ndarray)}
+    args = dict(bg=to_dev(bg, dev), means3D=t["means3D"], opac=t["opacities"], view=to_dev(cam["viewmatrix"], dev),
+                proj=to_dev(cam["projmatrix"], dev), campos=to_dev(cam["campos"], dev))
+    if mode == "sh":
+        colors, scales, rots, cov, sh, deg = e, t["scales"], t["rotations"], e, t["shs"], g["sh_degree"]
+    else:
+        colors, scales, rots, cov, sh, deg = t["colors"], e, e, t["cov3D"], e, 0
+    out = _C.rasterize_gaussians(args["bg"], args["means3D"], colors, args["opac"], scales, rots, 1.0, cov, args["view"],
+                                 args["proj"], cam["tanfovx"], cam["tanfovy"], cam["H"], cam["W"], sh, deg,
+                                 args["campos"], False, debug)
+    R, color, depth, alpha, radii, geomB, binB, imgB = out
+    return dict(R=R, color=color, depth=depth, alpha=alpha, radii=radii, geom=geomB, bin=binB, img=imgB, args=args,
+                colors=colors, scales=scales, rots=rots, cov=cov, sh=sh, deg=deg, P=t["means3D"].shape[0], W=cam["W"],
+                H=cam["H"], cam=cam)
+
+
+def hip_query(f, what):
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    return _C.query_state(what, f["P"], f["R"], f["W"], f["H"], f["geom"], f["bin"], f["img"]).cpu().numpy()
+
+
+def hip_backward(f, dL_dcolor, dL_ddepth, dL_dalpha, debug=False):
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    a, cam = f["args"], f["cam"]
+    dev = a["means3D"].device
+    out = _C.rasterize_gaussians_backward(
+        a["bg"], a["means3D"], f["radii"], f["colors"], f["scales"], f["rots"], 1.0, f["cov"], a["view"], a["proj"],
+        cam["tanfovx"], cam["tanfovy"], to_dev(dL_dcolor, dev), to_dev(dL_ddepth, dev), to_dev(dL_dalpha, dev), f["sh"],
+        f["deg"], a["campos"], f["geom"], f["R"], f["bin"], f["img"], f["alpha"], debug)
+    names = ["dL_dmean2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
+    return {n: o.cpu().numpy() for n, o in zip(names, out)}
+
+
+def assert_close(name, got, want, tol=1e-4, mask=None, max_bad_frac=0.0):
+    """|got - want| <= tol * max(1, |want|, scale) elementwise, where scale = the tensor's 99.9th percentile magnitude
+    (sums of many +/- terms are accurate relative to the terms, not to the possibly cancelled result)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if got.size == 0:
+        return
+    scale = max(1.0, float(np.percentile(np.abs(want), 99.9)))
+    err = np.abs(got - want)
+    bound = tol * np.maximum(np.abs(want), scale)
+    bad = err > bound
+    if mask is not None:
+        bad &= mask
+    frac = bad.mean()
+    assert frac <= max_bad_frac, f"{name}: {bad.sum()} / {bad.size} elements off; max err {err[bad].max():.3e} (scale {scale:.3e})"
