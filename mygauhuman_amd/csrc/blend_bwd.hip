@@ -1,18 +1,20 @@
 // blend_bwd.hip -- per-pixel backward of the alpha blend (replaces renderCUDA, CR/backward.cu:399-587).
 //
-// Same tile/quadrant decomposition as blend_fwd.hip (NW waves per 16x16 tile, each lane owns SLOTS = 4/NW pixels,
-// one per 8x8 quadrant).  The list is replayed back to front from each pixel's n_contrib / final_T.
+// Same decomposition as blend_fwd.hip: one independent wave per SLOTS quadrants of a tile, the tile's list is
+// replayed back to front from each pixel's n_contrib / final_T, 64 entries at a time, culled against the wave's
+// pixel rectangle (and against the wave's largest n_contrib) and compacted into LDS.
 //
-// Gradient accumulation, MI355X-first: the reference issues nine global atomicAdds per contributing
-// (pixel, Gaussian) pair (CR/backward.cu:538,574-584).  Here, per Gaussian and per wave,
-//   1. a lane first sums its SLOTS pixels in registers,
-//   2. four DPP steps (quad_perm x2, row_ror 4/8) give every 16-lane row its row total -- no LDS, no shuffles,
-//   3. lane (row r, k < 9) adds value k of its row into a per-tile LDS accumulator with ONE ds_add_f32
-//      wave-instruction (36 active lanes),
-//   4. after the batch, the tile flushes the LDS accumulators with float atomics into a packed 64-byte gradient row
-//      per Gaussian (16 lanes per row => each memory-side atomic request carries a whole Gaussian), skipping zeros.
-// That is one 64-B atomic request per (Gaussian, tile) instance instead of 9 x (pixels hit) scattered atomics.
-// A ballot skips all of it when no lane of the wave is hit by the Gaussian.
+// Gradient accumulation, wave64-first.  The reference issues nine global atomicAdds per contributing
+// (pixel, Gaussian) pair (CR/backward.cu:538,574-584).  Here survivors are processed four at a time and their
+// 4 x 9 per-lane partial sums are reduced TOGETHER:
+//   1. v_permlane32_swap on (a, b) and (c, d) + add   -> lanes 0-31 hold a, lanes 32-63 hold b  (resp. c, d)
+//   2. v_permlane16_swap on (ab, cd) + add            -> the four 16-lane rows hold a, c, b, d
+//   3. four DPP row steps (quad_perm x2, row_ror 4/8) -> every lane of a row holds that Gaussian's total
+// = 10 instructions per value for FOUR Gaussians (2.5 per Gaussian-value instead of 6 for a plain wave reduction),
+// and the result is already laid out for one atomic wave-instruction: lane (row r, column k < 9) adds value k of
+// row r's Gaussian into that Gaussian's packed 64-byte gradient row (GROW floats: one memory-side request per
+// Gaussian row instead of 9 scattered ones).  Ballots skip the exp / the reduction / the atomics whenever no lane
+// is hit.
 #include "gsr_common.h"
 
 namespace gsr {
@@ -35,39 +37,50 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x128>(v);  // row_ror 8
   return v;
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// lanes 0-31: sum over the wave of a; lanes 32-63: sum over the wave of b (both still spread over 32 lanes)
+__device__ __forceinline__ float fold32(float a, float b) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// x rows [x0 x1 x2 x3], y rows [y0 y1 y2 y3] -> rows [x0+x1, y0+y1, x2+x3, y2+y3]
+__device__ __forceinline__ float fold16(float x, float y) {
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
 
-constexpr int NACC = 9;        // mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, r, g, b
-constexpr int ACC_STRIDE = 9;  // floats per Gaussian in the LDS accumulator (odd stride: conflict-free rows)
+constexpr int NACC = 9;  // mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, r, g, b  (GROW row columns 0..8)
 
-template <int NW>
-__global__ __launch_bounds__(WAVE *NW) void blend_backward_kernel(const BlendBwdArgs a) {
-  constexpr int SLOTS = 4 / NW;
-  constexpr int BATCH = WAVE * NW;
-  __shared__ float4 s0[BATCH];
-  __shared__ float4 s1[BATCH];
-  __shared__ float4 s2[BATCH];
-  __shared__ uint32_t s_id[BATCH];
-  __shared__ float s_acc[BATCH * ACC_STRIDE];
-  __shared__ uint32_t s_max[NW];
+template <int SLOTS>
+__global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs a) {
+  constexpr int WPT = 4 / SLOTS;
+  __shared__ float4 s0[WAVE];     // x, y, conic_a, conic_b
+  __shared__ float4 s1[WAVE];     // conic_c, opacity, depth, r
+  __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
+  __shared__ uint32_t s_id[WAVE + 4];
 
-  const uint32_t tile = xcd_remap_b(blockIdx.x, gridDim.x);
+  const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);
+  const uint32_t tile = item / WPT, part = item % WPT;
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
-  const int wave = threadIdx.x / WAVE;
-  const uint32_t lane = lane_id();
+  const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
   const size_t plane = (size_t)a.H * a.W;
   const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
   float pxf[SLOTS], pyf[SLOTS], T[SLOTS], Tfin[SLOTS], bgdot[SLOTS];
   float dpix0[SLOTS], dpix1[SLOTS], dpix2[SLOTS], ddep[SLOTS], dalp[SLOTS];
   float arec0[SLOTS], arec1[SLOTS], arec2[SLOTS], adep[SLOTS], aalp[SLOTS];
   float lalpha[SLOTS], lc0[SLOTS], lc1[SLOTS], lc2[SLOTS], ldep[SLOTS];
   int lastc[SLOTS];
-  uint32_t maxlast = 0;
+  const int q0 = (int)part * SLOTS, q1 = q0 + SLOTS - 1;
+  const float rx0 = (float)(tx * TILE + (q0 & 1) * 8), rx1 = (float)(tx * TILE + (q1 & 1) * 8 + 7);
+  const float ry0 = (float)(ty * TILE + (q0 >> 1) * 8), ry1 = (float)(ty * TILE + (q1 >> 1) * 8 + 7);
+  int maxlast = 0;
 #pragma unroll
   for (int s = 0; s < SLOTS; s++) {
-    const int q = wave * SLOTS + s;
+    const int q = q0 + s;
     const int px = tx * TILE + (q & 1) * 8 + (int)(lane & 7);
     const int py = ty * TILE + (q >> 1) * 8 + (int)(lane >> 3);
     const bool inside = px < a.W && py < a.H;
@@ -82,131 +95,142 @@ __global__ __launch_bounds__(WAVE *NW) void blend_backward_kernel(const BlendBwd
     dpix2[s] = inside ? a.dL_dpix[2 * plane + p] : 0.f;
     ddep[s] = inside ? a.dL_ddepth[p] : 0.f;
     dalp[s] = inside ? a.dL_dalpha[p] : 0.f;
-    bgdot[s] = a.bg[0] * dpix0[s] + a.bg[1] * dpix1[s] + a.bg[2] * dpix2[s];
+    bgdot[s] = bg0 * dpix0[s] + bg1 * dpix1[s] + bg2 * dpix2[s];
     arec0[s] = arec1[s] = arec2[s] = adep[s] = aalp[s] = 0.f;
     lalpha[s] = lc0[s] = lc1[s] = lc2[s] = ldep[s] = 0.f;
-    maxlast = max(maxlast, (uint32_t)lastc[s]);
+    maxlast = max(maxlast, lastc[s]);
   }
-  // block-wide max of n_contrib: list entries at front positions >= maxlast contribute to no pixel of the tile
-  {
-    uint32_t m = maxlast;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
-    if (lane == 0) s_max[wave] = m;
-    for (int e = threadIdx.x; e < BATCH * ACC_STRIDE; e += BATCH) s_acc[e] = 0.f;
-    __syncthreads();
-    m = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) m = max(m, s_max[w]);
-    maxlast = m;
-  }
-  const int skip = n - (int)maxlast;  // entries idx < skip (counted from the back) are behind every last contributor
+  for (int d = 32; d >= 1; d >>= 1) maxlast = max(maxlast, __shfl_xor(maxlast, d, WAVE));
+  // list entries at front positions >= maxlast contribute to none of this wave's pixels
+  const int skip = n - maxlast;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int row = (int)(lane >> 4), kcol = (int)(lane & 15);
 
-  // per-lane constants for step 3 (which accumulator column this lane feeds)
-  const int kcol = (int)(lane & 15);
-
-  for (int base = skip; base < n; base += BATCH) {
-    const int idx = base + (int)threadIdx.x;
+  for (int base = skip; base < n; base += WAVE) {
+    // ---- fetch 64 entries (from the back), cull, compact into LDS in back-to-front order
+    const int idx = base + (int)lane;
+    bool keep = false;
+    float4 r0 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
+    const float4 *src = nullptr;
+    uint32_t id = 0;
     if (idx < n) {
-      const uint32_t id = a.point_list[range.y - 1 - idx];
-      const float4 *src = reinterpret_cast<const float4 *>(a.recs + id);
-      s_id[threadIdx.x] = id;
-      s0[threadIdx.x] = src[0];
-      s1[threadIdx.x] = src[1];
-      s2[threadIdx.x] = src[2];
+      id = a.point_list[range.y - 1 - idx];
+      src = reinterpret_cast<const float4 *>(a.recs + id);
+      r0 = src[0];
+      r2 = src[2];
+      keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
     }
-    __syncthreads();
-    const int cnt = min(BATCH, n - base);
-    for (int j = 0; j < cnt; j++) {
-      const int fpos = n - 1 - (base + j);  // 0-based position from the front (= contributor after the decrement)
-      const float4 g0 = s0[j];
-      const float4 g1 = s1[j];
-      const float4 g2 = s2[j];
-      float acc[NACC];
+    const uint64_t kmask = __ballot(keep);
+    const int cnt = __builtin_popcountll(kmask);
+    if (keep) {
+      const int slot = __builtin_popcountll(kmask & lt);
+      const float4 r1 = src[1];
+      s0[slot] = r0;
+      s1[slot] = r1;
+      s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)));
+      s_id[slot] = id;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int g = 0; g < cnt; g += 4) {
+      float acc[4][NACC];
+      uint32_t anyhit = 0;
 #pragma unroll
-      for (int k = 0; k < NACC; k++) acc[k] = 0.f;
-      bool any = false;
+      for (int u = 0; u < 4; u++) {
 #pragma unroll
-      for (int s = 0; s < SLOTS; s++) {
-        const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
-        const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-        const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-        const float alpha = fminf(0.99f, g1.y * G);
-        const bool hit = (fpos < lastc[s]) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        if (__ballot(hit) != 0ull) {
-          any = true;
-          const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
-          const float Tn = T[s] * rc;
-          const float w = alpha * Tn;  // dchannel_dcolor
-          const float one_m_la = 1.f - lalpha[s];
-          const float r0 = lalpha[s] * lc0[s] + one_m_la * arec0[s];
-          const float r1 = lalpha[s] * lc1[s] + one_m_la * arec1[s];
-          const float r2 = lalpha[s] * lc2[s] + one_m_la * arec2[s];
-          const float rd = lalpha[s] * ldep[s] + one_m_la * adep[s];
-          const float ra = lalpha[s] + one_m_la * aalp[s];
-          float dL_dopa = (g1.w - r0) * dpix0[s] + (g2.x - r1) * dpix1[s] + (g2.y - r2) * dpix2[s];
-          dL_dopa += (g1.z - rd) * ddep[s];
-          dL_dopa += (1.f - ra) * dalp[s];
-          dL_dopa *= Tn;
-          dL_dopa += (-Tfin[s] * rc) * bgdot[s];
-          const float dL_dG = g1.y * dL_dopa;
-          const float gdx = G * dx, gdy = G * dy;
-          const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
-          const float dG_ddely = -gdy * g1.x - gdx * g0.w;
-          const float m = hit ? 1.f : 0.f;
-          const float hG = m * dL_dG;
-          acc[0] += hG * dG_ddelx * ddelx_dx;
-          acc[1] += hG * dG_ddely * ddely_dy;
-          acc[2] += -0.5f * gdx * dx * hG;
-          acc[3] += -0.5f * gdx * dy * hG;
-          acc[4] += -0.5f * gdy * dy * hG;
-          acc[5] += m * G * dL_dopa;
-          const float hw = m * w;
-          acc[6] += hw * dpix0[s];
-          acc[7] += hw * dpix1[s];
-          acc[8] += hw * dpix2[s];
-          // commit the replay state for the lanes that were hit
-          T[s] = hit ? Tn : T[s];
-          arec0[s] = hit ? r0 : arec0[s];
-          arec1[s] = hit ? r1 : arec1[s];
-          arec2[s] = hit ? r2 : arec2[s];
-          adep[s] = hit ? rd : adep[s];
-          aalp[s] = hit ? ra : aalp[s];
-          lalpha[s] = hit ? alpha : lalpha[s];
-          lc0[s] = hit ? g1.w : lc0[s];
-          lc1[s] = hit ? g2.x : lc1[s];
-          lc2[s] = hit ? g2.y : lc2[s];
-          ldep[s] = hit ? g1.z : ldep[s];
+        for (int k = 0; k < NACC; k++) acc[u][k] = 0.f;
+        if (g + u < cnt) {  // wave-uniform
+          const float4 g0 = s0[g + u];
+          const float4 g1 = s1[g + u];
+          const float4 g2 = s2[g + u];
+          const int fpos = (int)__float_as_uint(g2.w);  // 0-based position from the front
+#pragma unroll
+          for (int s = 0; s < SLOTS; s++) {
+            const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
+            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
+            const float p2 = power * 1.4426950408889634f;
+            const bool pre = (fpos < lastc[s]) && !(power > 0.0f) && (p2 + g2.z >= -0.02f);
+            if (__ballot(pre) != 0ull) {
+              const float G = __builtin_amdgcn_exp2f(p2);
+              const float alpha = fminf(0.99f, g1.y * G);
+              const bool hit = pre && !(alpha < 1.0f / 255.0f);
+              if (__ballot(hit) != 0ull) {
+                anyhit |= 1u << u;
+                const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = T[s] * rc;
+                const float w = alpha * Tn;  // dchannel_dcolor
+                const float one_m_la = 1.f - lalpha[s];
+                const float q0r = lalpha[s] * lc0[s] + one_m_la * arec0[s];
+                const float q1r = lalpha[s] * lc1[s] + one_m_la * arec1[s];
+                const float q2r = lalpha[s] * lc2[s] + one_m_la * arec2[s];
+                const float rd = lalpha[s] * ldep[s] + one_m_la * adep[s];
+                const float ra = lalpha[s] + one_m_la * aalp[s];
+                float dL_dopa = (g1.w - q0r) * dpix0[s] + (g2.x - q1r) * dpix1[s] + (g2.y - q2r) * dpix2[s];
+                dL_dopa += (g1.z - rd) * ddep[s];
+                dL_dopa += (1.f - ra) * dalp[s];
+                dL_dopa *= Tn;
+                dL_dopa += (-Tfin[s] * rc) * bgdot[s];
+                const float m = hit ? 1.f : 0.f;
+                const float hG = m * (g1.y * dL_dopa);  // dL_dG on hit lanes
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
+                const float dG_ddely = -gdy * g1.x - gdx * g0.w;
+                acc[u][0] += hG * dG_ddelx * ddelx_dx;
+                acc[u][1] += hG * dG_ddely * ddely_dy;
+                acc[u][2] += -0.5f * gdx * dx * hG;
+                acc[u][3] += -0.5f * gdx * dy * hG;
+                acc[u][4] += -0.5f * gdy * dy * hG;
+                acc[u][5] += m * G * dL_dopa;
+                const float hw = m * w;
+                acc[u][6] += hw * dpix0[s];
+                acc[u][7] += hw * dpix1[s];
+                acc[u][8] += hw * dpix2[s];
+                // commit the replay state on the lanes that were hit
+                T[s] = hit ? Tn : T[s];
+                arec0[s] = hit ? q0r : arec0[s];
+                arec1[s] = hit ? q1r : arec1[s];
+                arec2[s] = hit ? q2r : arec2[s];
+                adep[s] = hit ? rd : adep[s];
+                aalp[s] = hit ? ra : aalp[s];
+                lalpha[s] = hit ? alpha : lalpha[s];
+                lc0[s] = hit ? g1.w : lc0[s];
+                lc1[s] = hit ? g2.x : lc1[s];
+                lc2[s] = hit ? g2.y : lc2[s];
+                ldep[s] = hit ? g1.z : ldep[s];
+              }
+            }
+          }
         }
       }
-      if (any) {  // wave-uniform
+      if (anyhit) {  // wave-uniform
+        // four Gaussians x nine values reduced together; afterwards row 0/1/2/3 = Gaussian g+0 / g+2 / g+1 / g+3
+        float red[NACC];
 #pragma unroll
-        for (int k = 0; k < NACC; k++) acc[k] = row16_sum(acc[k]);
-        float v = acc[0];
+        for (int k = 0; k < NACC; k++) red[k] = row16_sum(fold16(fold32(acc[0][k], acc[1][k]), fold32(acc[2][k], acc[3][k])));
+        float v = red[0];
 #pragma unroll
-        for (int k = 1; k < NACC; k++) v = (kcol == k) ? acc[k] : v;
-        if (kcol < NACC) atomicAdd(&s_acc[j * ACC_STRIDE + kcol], v);
-      }
-    }
-    __syncthreads();
-    // flush: 16 lanes per Gaussian row -> one 64-byte line of grad_rows per (Gaussian, tile) instance
-    for (int e = threadIdx.x; e < cnt * 16; e += BATCH) {
-      const int j = e >> 4, k = e & 15;
-      if (k < NACC) {
-        const float v = s_acc[j * ACC_STRIDE + k];
-        if (v != 0.f) {
-          atomicAdd(&a.grad_rows[(size_t)s_id[j] * GROW + k], v);
-          s_acc[j * ACC_STRIDE + k] = 0.f;
+        for (int k = 1; k < NACC; k++) v = (kcol == k) ? red[k] : v;
+        const int u_of_row = ((row & 1) << 1) | (row >> 1);  // 0,2,1,3
+        const bool live = kcol < NACC && ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
+        if (live) {
+          const uint32_t gid = s_id[g + u_of_row];
+          atomicAdd(&a.grad_rows[(size_t)gid * GROW + kcol], v);
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();  // keep the next batch's LDS writes behind this batch's reads
   }
 }
 
-static int g_blend_bwd_nw = 2;
+static int g_blend_bwd_nw = 4;
 int set_blend_backward_waves(int nw) {
-  if (nw != 1 && nw != 2 && nw != 4) return GSR_EINVAL;
+  if (nw != 1 && nw != 2 && nw != 4) {
+    set_error("blend_bwd_waves must be 1, 2 or 4");
+    return GSR_EINVAL;
+  }
   g_blend_bwd_nw = nw;
   return GSR_OK;
 }
@@ -215,9 +239,9 @@ int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
   switch (g_blend_bwd_nw) {
-    case 1: hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(tiles), dim3(WAVE * 1), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(blend_backward_kernel<2>, dim3(tiles), dim3(WAVE * 2), 0, stream, a); break;
-    default: hipLaunchKernelGGL(blend_backward_kernel<4>, dim3(tiles), dim3(WAVE * 4), 0, stream, a); break;
+    case 1: hipLaunchKernelGGL(blend_backward_kernel<4>, dim3(tiles), dim3(WAVE), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(blend_backward_kernel<2>, dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
+    default: hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
   }
   return GSR_OK;
 }

@@ -182,6 +182,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
           rec.r = rgb.x;
           rec.g = rgb.y;
           rec.b = rgb.z;
+          // Conservative cull box for the blend kernels (never changes a result): a pixel can only pass the
+          // alpha >= 1/255 test if power >= -ln(255*opacity), i.e. inside the ellipse d^T conic d <= 2 tau, whose
+          // bounding box has half-extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy) (cov = inverse conic).
+          const float o = rec.opacity, t255 = 255.0f * o;
+          float hx = __builtin_inff(), hy = __builtin_inff();
+          if (o == o) {
+            if (!(t255 >= 1.0f)) {
+              hx = hy = -1.0e30f;  // alpha <= opacity < 1/255 everywhere
+            } else if (cv.x > 0.f && cv.z > 0.f && det > 0.f) {
+              const float tau2 = 2.0f * (logf(t255) + 0.02f);
+              hx = sqrtf(tau2 * cv.x) * 1.0001f + 0.01f;
+              hy = sqrtf(tau2 * cv.z) * 1.0001f + 0.01f;
+            }
+          }
+          rec.hx = hx;
+          rec.hy = hy;
         }
       }
     }
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
     float4 *dst = reinterpret_cast<float4 *>(a.geom.recs + i);
     dst[0] = make_float4(rec.x, rec.y, rec.conic_a, rec.conic_b);
     dst[1] = make_float4(rec.conic_c, rec.opacity, rec.depth, rec.r);
-    dst[2] = make_float4(rec.g, rec.b, 0.f, 0.f);
+    dst[2] = make_float4(rec.g, rec.b, rec.hx, rec.hy);
   }
   // block-local inclusive scan of tiles_touched (first level of the device-wide scan)
   const uint32_t incl_w = wave_incl_scan(tiles);

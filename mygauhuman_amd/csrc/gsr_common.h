@@ -18,7 +18,7 @@ constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess / duplicate block (t
 struct alignas(16) SplatRec {
   float x, y, conic_a, conic_b;        // pixel centre, conic.x, conic.y
   float conic_c, opacity, depth, r;    // conic.z (CUDA float3 .z), opacity, view depth, red
-  float g, b, pad0, pad1;
+  float g, b, hx, hy;                  // half-extents (px) of the box outside which alpha < 1/255 for sure (cull only)
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec layout");
 

@@ -56,38 +56,56 @@ __global__ __launch_bounds__(SORT_BLOCK) void radix_hist_kernel(const K *__restr
   hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s;
 }
 
-// in-place exclusive scan of `count` uint32 words by one 1024-thread block
-__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *data, size_t count) {
-  __shared__ uint32_t wtot[1024 / WAVE];
-  const size_t chunk = (count + 1023) / 1024;
-  const size_t lo = (size_t)threadIdx.x * chunk;
-  const size_t hi = lo + chunk < count ? lo + chunk : count;
-  uint32_t s = 0;
-  for (size_t i = lo; i < hi; i++) s += data[i];
-  const uint32_t incl_w = wave_incl_scan(s);
-  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  if (lane == WAVE - 1) wtot[wave] = incl_w;
+// Scan of the digit-major [256][nblocks] histogram, one workgroup per digit row: row d becomes the exclusive
+// prefix over the blocks, and totals[d] the digit's global count.  (The scatter kernel turns the 256 totals into
+// digit bases itself, so a pass needs no single-workgroup scan over 256*nblocks words.)
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ totals,
+                                                        uint32_t nblocks) {
+  __shared__ uint32_t wtot[256 / WAVE];
+  __shared__ uint32_t carry_s;
+  uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
+  if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  uint32_t run = incl_w - s;
-  for (int w = 0; w < wave; w++) run += wtot[w];
-  for (size_t i = lo; i < hi; i++) {
-    const uint32_t v = data[i];
-    data[i] = run;
-    run += v;
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  for (uint32_t base = 0; base < nblocks; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblocks ? row[i] : 0u;
+    const uint32_t incl_w = wave_incl_scan(v);
+    if (lane == WAVE - 1) wtot[wave] = incl_w;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wtot[w];
+    const uint32_t carry = carry_s;
+    if (i < nblocks) row[i] = carry + woff + incl_w - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + woff + incl_w;
+    __syncthreads();
   }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
 template <typename K>
 __global__ __launch_bounds__(SORT_BLOCK) void radix_scatter_kernel(const K *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                                    K *__restrict__ kout, uint32_t *__restrict__ vout, size_t n,
                                                                    int shift, const uint32_t *__restrict__ hist,
-                                                                   uint32_t nblocks) {
+                                                                   const uint32_t *__restrict__ totals, uint32_t nblocks) {
   __shared__ volatile uint32_t wcount[SORT_BLOCK / WAVE][256];
+  __shared__ uint32_t dtot[SORT_BLOCK / WAVE];
   const int wave = threadIdx.x / WAVE;
   const uint32_t lane = lane_id();
   const uint64_t lt = lanemask_lt();
   for (int w = 0; w < SORT_BLOCK / WAVE; w++) wcount[w][threadIdx.x] = 0;
-  const uint32_t gbase = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+  // digit base = exclusive scan of the 256 digit totals (thread d owns digit d) + this block's prefix in row d
+  uint32_t gbase;
+  {
+    const uint32_t tot = totals[threadIdx.x];
+    const uint32_t incl_w = wave_incl_scan(tot);
+    if (lane == WAVE - 1) dtot[wave] = incl_w;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += dtot[w];
+    gbase = woff + incl_w - tot + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+  }
   __syncthreads();
   K k[SORT_ITEMS];
   uint32_t v[SORT_ITEMS];
@@ -155,10 +173,10 @@ static int radix_sort_impl(size_t n, const K *in_k, const uint32_t *in_v, K *x_k
     const int shift = 8 * p;
     hipLaunchKernelGGL(radix_hist_kernel<K>, dim3(nblocks), dim3(SORT_BLOCK), 0, stream, src_k, n, shift, hist, nblocks);
     GSR_LAUNCH_CHECK(stream, debug);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, (size_t)256 * nblocks);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, stream, hist, hist + (size_t)256 * nblocks, nblocks);
     GSR_LAUNCH_CHECK(stream, debug);
     hipLaunchKernelGGL(radix_scatter_kernel<K>, dim3(nblocks), dim3(SORT_BLOCK), 0, stream, src_k, src_v, dst_k, dst_v, n,
-                       shift, hist, nblocks);
+                       shift, hist, hist + (size_t)256 * nblocks, nblocks);
     GSR_LAUNCH_CHECK(stream, debug);
     src_k = dst_k;
     src_v = dst_v;

@@ -28,8 +28,8 @@ def waves(request):
     _lib.set_tuning("blend_fwd_waves", request.param)
     _lib.set_tuning("blend_bwd_waves", request.param)
     yield request.param
-    _lib.set_tuning("blend_fwd_waves", 2)
-    _lib.set_tuning("blend_bwd_waves", 2)
+    _lib.set_tuning("blend_fwd_waves", 4)
+    _lib.set_tuning("blend_bwd_waves", 4)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"P{c[0]}_{c[1]}x{c[2]}" for c in CASES])
