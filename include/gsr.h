@@ -70,7 +70,8 @@ int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const
  *   background[3]; means3D[P][3]; colors_precomp[P][3]; opacities[P]; scales[P][3]; rotations[P][4] (r,x,y,z);
  *   cov3D_precomp[P][6]; viewmatrix/projmatrix[16] (row-vector convention); cam_pos[3];
  *   out_color[3][H][W], out_depth[H][W], out_alpha[H][W] (alpha = sum of blending weights), radii[P] (may be null).
- * Outputs must be zero-filled by the caller like the reference binding does (DGR/rasterize_points.cu:69-72);
+ * Every element of the outputs is written when P > 0 (the reference binding zero-fills them first,
+ * DGR/rasterize_points.cu:69-72; callers only need that for P == 0);
  * *host_num_rendered receives the number of (Gaussian, tile) instances (the reference's return value). */
 int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc,
                           void *binning_user, gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M,
@@ -82,8 +83,10 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
                           int *radii, int debug, int *host_num_rendered, gsr_stream_t stream);
 
 /* Backward rasterisation, Rasterizer::backward (CR/rasterizer.h:58-89).  R = num_rendered of the forward call;
- * geom/binning/image buffers are the ones the forward call filled.  All dL_d* outputs must be zero-filled
- * (DGR/rasterize_points.cu:159-167): dL_dmean2D[P][3], dL_dconic[P][4], dL_dopacity[P], dL_dcolor[P][3],
+ * geom/binning/image buffers are the ones the forward call filled.  The library writes every element of the dL_d*
+ * outputs it owns, zeros for culled Gaussians (the reference relies on zero-filled tensors,
+ * DGR/rasterize_points.cu:159-167); dL_dsh / dL_dscale / dL_drot are only touched when shs / scales are given:
+ * dL_dmean2D[P][3], dL_dconic[P][4], dL_dopacity[P], dL_dcolor[P][3],
  * dL_dmean3D[P][3], dL_dcov3D[P][6], dL_dsh[P][M][3], dL_dscale[P][3], dL_drot[P][4].
  * `alphas` is accepted and ignored like in the reference kernel (CR/backward.cu:410). */
 int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height,

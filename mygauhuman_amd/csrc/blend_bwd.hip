@@ -49,7 +49,11 @@ __device__ __forceinline__ float fold16(float x, float y) {
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
-constexpr int NACC = 9;  // mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, r, g, b  (GROW row columns 0..8)
+// GROW row columns 0..8: with r = G * dL_dalpha(pair) and d = mean2D - pixel:
+//   [0] sum r*dx  [1] sum r*dy  [2] sum r*dx*dx  [3] sum r*dx*dy  [4] sum r*dy*dy  [5] sum r (= dL_dopacity)
+//   [6..8] dL_dcolor.  The geometric gradients are linear in these moments (CR/backward.cu:567-580):
+//   dL_dmean2D.x = -o (A m0 + B m1) W/2, .y = -o (C m1 + B m0) H/2, dL_dconic = -o/2 (m2, m3, m4); see preprocess_bwd.hip.
+constexpr int NACC = 9;
 
 template <int SLOTS>
 __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs a) {
@@ -66,7 +70,6 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
   const size_t plane = (size_t)a.H * a.W;
-  const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
   float pxf[SLOTS], pyf[SLOTS], T[SLOTS], Tfin[SLOTS], bgdot[SLOTS];
@@ -157,49 +160,40 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
               const float G = __builtin_amdgcn_exp2f(p2);
               const float alpha = fminf(0.99f, g1.y * G);
               const bool hit = pre && !(alpha < 1.0f / 255.0f);
-              if (__ballot(hit) != 0ull) {
-                anyhit |= 1u << u;
+              if (__ballot(hit) != 0ull) anyhit |= 1u << u;
+              if (hit) {  // exec-masked body: state and sums change on hit lanes only
                 const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
                 const float Tn = T[s] * rc;
                 const float w = alpha * Tn;  // dchannel_dcolor
                 const float one_m_la = 1.f - lalpha[s];
-                const float q0r = lalpha[s] * lc0[s] + one_m_la * arec0[s];
-                const float q1r = lalpha[s] * lc1[s] + one_m_la * arec1[s];
-                const float q2r = lalpha[s] * lc2[s] + one_m_la * arec2[s];
-                const float rd = lalpha[s] * ldep[s] + one_m_la * adep[s];
-                const float ra = lalpha[s] + one_m_la * aalp[s];
-                float dL_dopa = (g1.w - q0r) * dpix0[s] + (g2.x - q1r) * dpix1[s] + (g2.y - q2r) * dpix2[s];
-                dL_dopa += (g1.z - rd) * ddep[s];
-                dL_dopa += (1.f - ra) * dalp[s];
+                arec0[s] = lalpha[s] * lc0[s] + one_m_la * arec0[s];
+                arec1[s] = lalpha[s] * lc1[s] + one_m_la * arec1[s];
+                arec2[s] = lalpha[s] * lc2[s] + one_m_la * arec2[s];
+                adep[s] = lalpha[s] * ldep[s] + one_m_la * adep[s];
+                aalp[s] = lalpha[s] + one_m_la * aalp[s];
+                float dL_dopa = (g1.w - arec0[s]) * dpix0[s] + (g2.x - arec1[s]) * dpix1[s] + (g2.y - arec2[s]) * dpix2[s];
+                dL_dopa += (g1.z - adep[s]) * ddep[s];
+                dL_dopa += (1.f - aalp[s]) * dalp[s];
                 dL_dopa *= Tn;
                 dL_dopa += (-Tfin[s] * rc) * bgdot[s];
-                const float m = hit ? 1.f : 0.f;
-                const float hG = m * (g1.y * dL_dopa);  // dL_dG on hit lanes
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * g0.z - gdy * g0.w;
-                const float dG_ddely = -gdy * g1.x - gdx * g0.w;
-                acc[u][0] += hG * dG_ddelx * ddelx_dx;
-                acc[u][1] += hG * dG_ddely * ddely_dy;
-                acc[u][2] += -0.5f * gdx * dx * hG;
-                acc[u][3] += -0.5f * gdx * dy * hG;
-                acc[u][4] += -0.5f * gdy * dy * hG;
-                acc[u][5] += m * G * dL_dopa;
-                const float hw = m * w;
-                acc[u][6] += hw * dpix0[s];
-                acc[u][7] += hw * dpix1[s];
-                acc[u][8] += hw * dpix2[s];
-                // commit the replay state on the lanes that were hit
-                T[s] = hit ? Tn : T[s];
-                arec0[s] = hit ? q0r : arec0[s];
-                arec1[s] = hit ? q1r : arec1[s];
-                arec2[s] = hit ? q2r : arec2[s];
-                adep[s] = hit ? rd : adep[s];
-                aalp[s] = hit ? ra : aalp[s];
-                lalpha[s] = hit ? alpha : lalpha[s];
-                lc0[s] = hit ? g1.w : lc0[s];
-                lc1[s] = hit ? g2.x : lc1[s];
-                lc2[s] = hit ? g2.y : lc2[s];
-                ldep[s] = hit ? g1.z : ldep[s];
+                // moments of r = G * dL_dalpha over the pixels; preprocess_bwd.hip turns them into dL_dmean2D / dL_dconic
+                const float r = G * dL_dopa;
+                const float rx = r * dx, ry = r * dy;
+                acc[u][0] += rx;
+                acc[u][1] += ry;
+                acc[u][2] += rx * dx;
+                acc[u][3] += rx * dy;
+                acc[u][4] += ry * dy;
+                acc[u][5] += r;
+                acc[u][6] += w * dpix0[s];
+                acc[u][7] += w * dpix1[s];
+                acc[u][8] += w * dpix2[s];
+                T[s] = Tn;
+                lalpha[s] = alpha;
+                lc0[s] = g1.w;
+                lc1[s] = g2.x;
+                lc2[s] = g2.y;
+                ldep[s] = g1.z;
               }
             }
           }

@@ -7,6 +7,7 @@
 //
 // Replaces: preprocessCUDA (CR/forward.cu:155-256), checkFrustum (CR/rasterizer_impl.cu:54-66),
 // cub::DeviceScan::InclusiveSum (:279), duplicateWithKeys (:70-111), identifyTileRanges (:116-138).
+#include "expand.h"
 #include "gsr_common.h"
 
 namespace gsr {
@@ -271,59 +272,13 @@ int launch_scan_block_sums(const GeomState &g, int P, hipStream_t stream) {
   return GSR_OK;
 }
 
-// Key duplication, load-balanced: the block that preprocessed Gaussians [b*256, b*256+256) expands their
-// (Gaussian, tile) instances with one instance per lane, so key/value stores are fully coalesced
-// (the reference loops over the rect inside one thread, CR/rasterizer_impl.cu:98-109).  Emission order is
-// unchanged: Gaussian index, then tile row, then tile column.
+// Key duplication (CR/rasterizer_impl.cu:70-111), load-balanced (expand.h): key/value stores are fully coalesced.
 __global__ __launch_bounds__(PRE_BLOCK) void duplicate_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
                                                              uint64_t *keys, uint32_t *vals) {
-  __shared__ uint32_t s_incl[PRE_BLOCK];
-  __shared__ uint32_t s_depth[PRE_BLOCK];
-  __shared__ uint32_t s_rect[PRE_BLOCK];  // x0 | y0 << 10 | width << 20
-  const int first = blockIdx.x * PRE_BLOCK;
-  const int i = first + threadIdx.x;
-  const uint32_t bprefix = g.block_prefix[blockIdx.x];
-  uint32_t incl = 0, rect = 0, dbits = 0;
-  if (i < P) {
-    incl = g.block_incl[i];
-    g.point_offsets[i] = bprefix + incl;
-    const int rad = radii[i];
-    if (rad > 0) {
-      const float4 r0 = reinterpret_cast<const float4 *>(g.recs + i)[0];
-      const float4 r1 = reinterpret_cast<const float4 *>(g.recs + i)[1];
-      int x0, y0, x1, y1;
-      tile_rect(r0.x, r0.y, rad, gx, gy, x0, y0, x1, y1);
-      rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
-      dbits = __float_as_uint(r1.z);
-    }
-  } else {
-    incl = 0xFFFFFFFFu;  // never selected (see search below); overwritten for the tail next
-  }
-  s_incl[threadIdx.x] = incl;
-  s_depth[threadIdx.x] = dbits;
-  s_rect[threadIdx.x] = rect;
-  __syncthreads();
-  const int nvalid = min(PRE_BLOCK, P - first);
-  const uint32_t total = s_incl[nvalid - 1];
-  for (uint32_t k = threadIdx.x; k < total; k += PRE_BLOCK) {
-    // first j with incl[j] > k  (zero-tile Gaussians have incl[j] == incl[j-1] and are skipped)
-    int lo = 0, hi = nvalid - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (s_incl[mid] > k)
-        hi = mid;
-      else
-        lo = mid + 1;
-    }
-    const uint32_t start = lo == 0 ? 0u : s_incl[lo - 1];
-    const uint32_t local = k - start;
-    const uint32_t rc = s_rect[lo];
-    const uint32_t w = rc >> 20, x0 = rc & 1023u, y0 = (rc >> 10) & 1023u;
-    const uint32_t ty = y0 + local / w, tx = x0 + local % w;
-    const uint64_t key = ((uint64_t)(ty * (uint32_t)gx + tx) << 32) | (uint64_t)s_depth[lo];
-    keys[(size_t)bprefix + k] = key;
-    vals[(size_t)bprefix + k] = (uint32_t)(first + lo);
-  }
+  expand_block_instances(g, radii, P, gx, gy, true, [&](uint32_t inst, uint32_t gid, uint32_t tile, uint32_t dbits) {
+    keys[inst] = ((uint64_t)tile << 32) | (uint64_t)dbits;
+    vals[inst] = gid;
+  });
 }
 int launch_duplicate(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, uint64_t *keys, uint32_t *vals,
                      hipStream_t stream) {

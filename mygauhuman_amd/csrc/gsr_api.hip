@@ -187,12 +187,12 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
   if (rc != GSR_OK) return rc;
   *host_num_rendered = (int)R;
 
-  char *bchunk = binning_alloc(binning_user, binning_bytes((size_t)R));
+  char *bchunk = binning_alloc(binning_user, binning_bytes((size_t)R, tiles));
   if (!bchunk) {
     set_error("binning allocation callback returned null");
     return GSR_ENOMEM;
   }
-  BinningState bin = binning_from_chunk(bchunk, (size_t)R);
+  BinningState bin = binning_from_chunk(bchunk, (size_t)R, tiles);
 
   if (g_binning_mode == GSR_BINNING_TILE_BUCKET) {
     rc = bucket_binning(geom, radii, P, grid_x, grid_y, (size_t)R, bin, img.ranges, stream, debug);
@@ -312,6 +312,7 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
   pb.focal_y = height / (2.0f * tan_fovy);
   pb.focal_x = width / (2.0f * tan_fovx);
   pb.grad_rows = geom.grad_rows;
+  pb.recs = geom.recs;
   pb.dL_dmean2D = dL_dmean2D;
   pb.dL_dconic = dL_dconic;
   pb.dL_dopacity = dL_dopacity;

@@ -45,6 +45,8 @@ struct BinningState {  // per instance
   uint64_t *keys_s;  // sorted keys (final)
   uint32_t *vals_s;  // point_list (final)
   uint32_t *hist;    // radix histograms
+  uint32_t *tile_counts;  // [tiles] tile-bucket back-end (null if the buffer was carved without a tile count)
+  uint32_t *tile_cursor;  // [tiles]
 };
 struct ImageState {
   float *final_T;       // [H*W]
@@ -87,7 +89,7 @@ inline size_t geom_bytes(size_t P) {
   GeomState g = geom_from_chunk(nullptr, P);
   return reinterpret_cast<size_t>(g.grad_rows + P * GROW) + 256;
 }
-inline BinningState binning_from_chunk(char *chunk, size_t R) {
+inline BinningState binning_from_chunk(char *chunk, size_t R, size_t tiles = 0) {
   BinningState b;
   size_t n = R ? R : 1;
   carve(chunk, b.keys_a, n);
@@ -95,11 +97,16 @@ inline BinningState binning_from_chunk(char *chunk, size_t R) {
   carve(chunk, b.keys_s, n);
   carve(chunk, b.vals_s, n);
   carve(chunk, b.hist, sort_hist_words(n));
+  b.tile_counts = b.tile_cursor = nullptr;
+  if (tiles) {
+    carve(chunk, b.tile_counts, tiles);
+    carve(chunk, b.tile_cursor, tiles);
+  }
   return b;
 }
-inline size_t binning_bytes(size_t R) {
-  BinningState b = binning_from_chunk(nullptr, R);
-  return reinterpret_cast<size_t>(b.hist + sort_hist_words(R ? R : 1)) + 256;
+inline size_t binning_bytes(size_t R, size_t tiles) {
+  BinningState b = binning_from_chunk(nullptr, R, tiles ? tiles : 1);
+  return reinterpret_cast<size_t>(b.tile_cursor + (tiles ? tiles : 1)) + 256;
 }
 inline ImageState image_from_chunk(char *chunk, size_t npix, size_t tiles) {
   ImageState s;
@@ -188,6 +195,7 @@ struct PreprocessBwdArgs {
   int W, H;
   float tan_fovx, tan_fovy, focal_x, focal_y;
   const float *grad_rows;
+  const SplatRec *recs;
   float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };
 int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream);

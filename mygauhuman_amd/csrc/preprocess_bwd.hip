@@ -135,14 +135,52 @@ __device__ __forceinline__ void cov3d_backward(const float3 sc, float mod, const
 
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBwdArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.P || !(a.radii[i] > 0)) return;
+  if (i >= a.P) return;
+  if (!(a.radii[i] > 0)) {
+    // culled Gaussian: the reference leaves the zero-initialised outputs untouched (CR/backward.cu:156,367);
+    // writing the zeros here lets the host hand in uninitialised tensors (no separate fill kernels)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      a.dL_dmean2D[3 * (size_t)i + k] = 0.f;
+      a.dL_dcolor[3 * (size_t)i + k] = 0.f;
+      a.dL_dmean3D[3 * (size_t)i + k] = 0.f;
+      if (a.scales) a.dL_dscale[3 * (size_t)i + k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      a.dL_dconic[4 * (size_t)i + k] = 0.f;
+      if (a.scales) a.dL_drot[4 * (size_t)i + k] = 0.f;
+    }
+    a.dL_dopacity[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
+    if (a.shs)
+      for (int k = 0; k < a.M * 3; k++) a.dL_dsh[(size_t)i * a.M * 3 + k] = 0.f;
+    return;
+  }
   const float4 *row = reinterpret_cast<const float4 *>(a.grad_rows + (size_t)i * GROW);
-  const float4 g0 = row[0], g1 = row[1], g2 = row[2];
+  const float4 m0 = row[0], m1 = row[1], m2 = row[2];
+  // moments -> blend gradients (CR/backward.cu:567-584), conic / opacity from the forward's splat record
+  const float4 rec0 = reinterpret_cast<const float4 *>(a.recs + i)[0];
+  const float4 rec1 = reinterpret_cast<const float4 *>(a.recs + i)[1];
+  const float cA = rec0.z, cB = rec0.w, cC = rec1.x, op = rec1.y;
+  float4 g0, g1, g2;
+  g0.x = -op * (cA * m0.x + cB * m0.y) * (0.5f * a.W);  // dL_dmean2D.x
+  g0.y = -op * (cC * m0.y + cB * m0.x) * (0.5f * a.H);  // dL_dmean2D.y
+  g0.z = -0.5f * op * m0.z;                             // dL_dconic.x
+  g0.w = -0.5f * op * m0.w;                             // dL_dconic.y
+  g1.x = -0.5f * op * m1.x;                             // dL_dconic.w
+  g1.y = m1.y;                                          // dL_dopacity
+  g1.z = m1.z;                                          // dL_dcolor
+  g1.w = m1.w;
+  g2.x = m2.x;
   // unpack the blend gradients into the binding's tensors
   a.dL_dmean2D[3 * (size_t)i + 0] = g0.x;
   a.dL_dmean2D[3 * (size_t)i + 1] = g0.y;
+  a.dL_dmean2D[3 * (size_t)i + 2] = 0.f;
   a.dL_dconic[4 * (size_t)i + 0] = g0.z;
   a.dL_dconic[4 * (size_t)i + 1] = g0.w;
+  a.dL_dconic[4 * (size_t)i + 2] = 0.f;
   a.dL_dconic[4 * (size_t)i + 3] = g1.x;
   a.dL_dopacity[i] = g1.y;
   a.dL_dcolor[3 * (size_t)i + 0] = g1.z;
@@ -236,9 +274,11 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
   dm[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
   dm[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
 
-  if (a.shs)
+  if (a.shs) {
     sh_backward(a.D, mean, a.campos, a.shs + (size_t)i * a.M * 3, a.clamped[i], make_float3(g1.z, g1.w, g2.x), dm,
                 a.dL_dsh + (size_t)i * a.M * 3);
+    for (int k = (a.D + 1) * (a.D + 1) * 3; k < a.M * 3; k++) a.dL_dsh[(size_t)i * a.M * 3 + k] = 0.f;  // inactive bands
+  }
   a.dL_dmean3D[3 * (size_t)i + 0] = dm[0];
   a.dL_dmean3D[3 * (size_t)i + 1] = dm[1];
   a.dL_dmean3D[3 * (size_t)i + 2] = dm[2];

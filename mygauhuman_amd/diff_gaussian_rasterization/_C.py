@@ -48,10 +48,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         raise RuntimeError("rasterize_gaussians: tensors must live on a HIP device (no CPU path)")
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
-    out_alpha = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # the kernels write every pixel and every radius, so no fill kernels are needed unless nothing is launched
+    new = torch.zeros if P == 0 else torch.empty
+    out_color = new((3, H, W), dtype=torch.float32, device=dev)
+    out_depth = new((1, H, W), dtype=torch.float32, device=dev)
+    out_alpha = new((1, H, W), dtype=torch.float32, device=dev)
+    radii = new((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     rendered = C.c_int(0)
     if P != 0:
@@ -83,15 +85,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
     opts = dict(dtype=torch.float32, device=dev)
-    dL_dmeans3D = torch.zeros((P, 3), **opts)
-    dL_dmeans2D = torch.zeros((P, 3), **opts)
-    dL_dcolors = torch.zeros((P, 3), **opts)
-    dL_dconic = torch.zeros((P, 2, 2), **opts)
-    dL_dopacity = torch.zeros((P, 1), **opts)
-    dL_dcov3D = torch.zeros((P, 6), **opts)
-    dL_dsh = torch.zeros((P, M, 3), **opts)
-    dL_dscales = torch.zeros((P, 3), **opts)
-    dL_drotations = torch.zeros((P, 4), **opts)
+    # the backward-preprocess kernel writes every element of the tensors it owns (zeros for culled Gaussians)
+    new = torch.zeros if P == 0 else torch.empty
+    has_sr = scales.numel() != 0
+    dL_dmeans3D = new((P, 3), **opts)
+    dL_dmeans2D = new((P, 3), **opts)
+    dL_dcolors = new((P, 3), **opts)
+    dL_dconic = new((P, 2, 2), **opts)
+    dL_dopacity = new((P, 1), **opts)
+    dL_dcov3D = new((P, 6), **opts)
+    dL_dsh = new((P, M, 3), **opts)
+    dL_dscales = (new if has_sr else torch.zeros)((P, 3), **opts)
+    dL_drotations = (new if has_sr else torch.zeros)((P, 4), **opts)
     if P != 0:
         means3D, colors = _f32c(means3D, "means3D"), _f32c(colors, "colors")
         scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")

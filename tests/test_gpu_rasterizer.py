@@ -15,6 +15,7 @@ CASES = [
     (1, 48, 32, 2, 3, 0.05, 0.0),        # single Gaussian
     (20000, 256, 192, 3, 2, 0.01, 0.02),
     (700, 16, 16, 4, 1, 0.2, 0.0),       # one tile, everything overlaps, list longer than a batch
+    (9000, 24, 16, 5, 0, 0.3, 0.0),      # per-tile lists > 8192: the tile-bucket sort's merge path
 ]
 
 
@@ -32,9 +33,18 @@ def waves(request):
     _lib.set_tuning("blend_bwd_waves", 4)
 
 
+@pytest.fixture(scope="module", params=["radix", "bucket"])
+def binning(request):
+    from mygauhuman_amd import _lib
+    _lib.check(_lib.lib.gsr_set_binning_mode(_lib.BINNING_TILE_BUCKET if request.param == "bucket" else _lib.BINNING_GLOBAL_RADIX),
+               "gsr_set_binning_mode")
+    yield request.param
+    _lib.lib.gsr_set_binning_mode(_lib.DEFAULT_BINNING)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[f"P{c[0]}_{c[1]}x{c[2]}" for c in CASES])
 @pytest.mark.parametrize("mode", ["sh", "precomp"])
-def test_forward_matches_oracle(oracle, case, mode, waves):
+def test_forward_matches_oracle(oracle, case, mode, waves, binning):
     P, W, H, seed, deg, scale, behind = case
     cam, g = util.make_scene(P, W, H, seed, deg, scale, behind)
     bg = _bg(seed)

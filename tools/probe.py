@@ -21,8 +21,11 @@ def main():
     ap.add_argument("--deg", type=int, default=3)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--waves", type=str, default="1,2,4")
+    ap.add_argument("--binning", type=int, default=-1)
     a = ap.parse_args()
     dev = "cuda"
+    if a.binning >= 0:
+        _lib.check(_lib.lib.gsr_set_binning_mode(a.binning), "binning")
     cam, g = synthetic.uniform_scene(a.P, a.W, a.H, seed=0, sh_degree=a.deg)
     gt, mask = synthetic.loss_targets(a.W, a.H)
     t = {k: torch.from_numpy(v).to(dev) for k, v in g.items() if isinstance(v, np.ndarray)}
