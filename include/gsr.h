@@ -61,6 +61,14 @@ int gsr_get_binning_mode(void);
  * cooperate on one 16x16 tile (each lane then owns 4 / waves pixels). */
 int gsr_set_tuning(const char *key, int value);
 
+/* Optional stage timing with HIP events recorded on the caller's stream around the selected stages' kernels
+ * (no synchronisation until gsr_profile_read).  Stage ids: 0 forward preprocess, 1 scan, 2 binning (duplicate+sort+
+ * ranges or the tile-bucket kernels), 3 blend forward, 4 blend backward, 5 backward preprocess.  stage_mask bit i
+ * enables stage i; 0 disables.  gsr_profile_read returns the accumulated milliseconds and launch count of a stage. */
+int gsr_profile_enable(unsigned stage_mask);
+int gsr_profile_reset(void);
+int gsr_profile_read(int stage, double *total_ms, long *launches);
+
 /* present[i] = (view-space z of means3D[i]) > 0.2          (CR/rasterizer_impl.cu:54-66, CR/auxiliary.h:139-164) */
 int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                      uint8_t *present, gsr_stream_t stream);
@@ -82,6 +90,24 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
                           float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
                           int *radii, int debug, int *host_num_rendered, gsr_stream_t stream);
 
+/* Asynchronous forward (extension: no counterpart in the reference, which blocks on a device->host copy of R every
+ * call, CR/rasterizer_impl.cu:283).  The caller owns the three scratch buffers (gsr_geometry_bytes(P),
+ * gsr_binning_bytes(capacity, w, h), gsr_image_bytes(w, h)) and picks `binning_capacity` = the number of
+ * (Gaussian, tile) instances the binning buffer can hold; nothing is read back and the host never waits.
+ * dev_status is device uint32[2]: [0] = R, [1] = 1 if R > capacity, in which case NOTHING was rendered (outputs hold
+ * the background) and the call must be repeated with a larger capacity.  Always uses the tile-bucket binning.
+ * The matching backward is gsr_rasterize_backward with R = binning_capacity. */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_image_bytes(int width, int height);
+size_t gsr_binning_bytes(size_t binning_capacity, int width, int height);
+int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
+                                int D, int M, const float *background, int width, int height, const float *means3D,
+                                const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                                float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                                float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                                int *radii, int debug, uint32_t *dev_status, gsr_stream_t stream);
+
 /* Backward rasterisation, Rasterizer::backward (CR/rasterizer.h:58-89).  R = num_rendered of the forward call;
  * geom/binning/image buffers are the ones the forward call filled.  The library writes every element of the dL_d*
  * outputs it owns, zeros for culled Gaussians (the reference relies on zero-filled tensors,
@@ -98,6 +124,12 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
                            const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
                            float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
                            float *dL_dsh, float *dL_dscale, float *dL_drot, int debug, gsr_stream_t stream);
+
+/* Fused gradient of L = mean|color - gt| + lambda_alpha * mean (alpha - mask)^2 (train.py:261-262 with the masks set to
+ * the whole image): dL_dcolor[3][H][W] = sign(color - gt) / (3 H W), dL_dalpha[H][W] = 2 lambda (alpha - mask) / (H W). */
+int gsr_alpha_mask_loss_backward(int width, int height, const float *color, const float *alpha, const float *gt,
+                                 const float *mask, float lambda_alpha, float *dL_dcolor, float *dL_dalpha,
+                                 gsr_stream_t stream);
 
 /* Introspection of the private scratch buffers, for the parity tests only (copies device -> device):
  * what = one of GSR_Q_*; dst must hold the documented element count. */

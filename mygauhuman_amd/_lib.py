@@ -11,8 +11,10 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 # every symbol include/gsr.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning",
+    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
+    "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
+    "gsr_alpha_mask_loss_backward",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
     "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward",
 ]
@@ -41,6 +43,8 @@ def _load():
     lib.gsr_set_binning_mode.argtypes = [C.c_int]
     lib.gsr_get_binning_mode.restype = C.c_int
     lib.gsr_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.gsr_profile_enable.argtypes = [C.c_uint]
+    lib.gsr_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.gsr_mark_visible.argtypes = [C.c_int, fp, fp, fp, vp, vp]
     lib.gsr_rasterize_forward.argtypes = [
         ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp,
@@ -48,6 +52,18 @@ def _load():
     lib.gsr_rasterize_backward.argtypes = [
         C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp,
         C.c_float, C.c_float, ip, vp, vp, vp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int, vp]
+    lib.gsr_geometry_bytes.argtypes = [C.c_int]
+    lib.gsr_geometry_bytes.restype = sz
+    lib.gsr_image_bytes.argtypes = [C.c_int, C.c_int]
+    lib.gsr_image_bytes.restype = sz
+    lib.gsr_binning_bytes.argtypes = [sz, C.c_int, C.c_int]
+    lib.gsr_binning_bytes.restype = sz
+    lib.gsr_rasterize_forward_async.argtypes = [
+        vp, vp, sz, vp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_float, fp, fp, fp, fp, fp,
+        C.c_float, C.c_float, C.c_int, fp, fp, fp, ip, C.c_int, vp, vp]
+    lib.gsr_rasterize_forward_async.restype = C.c_int
+    lib.gsr_alpha_mask_loss_backward.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, C.c_float, fp, fp, vp]
+    lib.gsr_alpha_mask_loss_backward.restype = C.c_int
     lib.gsr_query_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_dist2_workspace_bytes.argtypes = [C.c_int]
     lib.gsr_dist2_workspace_bytes.restype = sz
@@ -79,6 +95,28 @@ def ptr(t):
     if t is None or t.numel() == 0:
         return None
     return t.data_ptr()
+
+
+PROF_STAGES = ["preprocess_fwd", "scan", "binning", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+
+
+def profile_enable(stages):
+    """stages: iterable of names from PROF_STAGES (empty = off)."""
+    mask = 0
+    for s in stages:
+        mask |= 1 << PROF_STAGES.index(s)
+    check(lib.gsr_profile_enable(mask), "gsr_profile_enable")
+    check(lib.gsr_profile_reset(), "gsr_profile_reset")
+
+
+def profile_read():
+    """{stage: (total_ms, launches)} accumulated since profile_enable()."""
+    out = {}
+    for i, s in enumerate(PROF_STAGES):
+        ms, n = C.c_double(0), C.c_long(0)
+        check(lib.gsr_profile_read(i, C.byref(ms), C.byref(n)), "gsr_profile_read")
+        out[s] = (ms.value, n.value)
+    return out
 
 
 def set_tuning(key, value):

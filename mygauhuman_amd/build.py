@@ -20,6 +20,7 @@ SOURCES = [
     ("blend_bwd.hip", []),
     ("preprocess_bwd.hip", []),
     ("lbs.hip", []),
+    ("loss.hip", []),
     ("gsr_api.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -59,15 +59,30 @@ def make_camera(W, H, fov_deg=50.0, R=None, T=None):
                 tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5), FoVx=fovx, FoVy=fovy)
 
 
-def ring_camera(W, H, k, n, radius=3.0, fov_deg=50.0):
-    """k-th of n cameras on a horizontal ring of `radius` looking at the origin (config 4 views)."""
-    ang = 2.0 * math.pi * k / n
-    eye = np.array([radius * math.sin(ang), 0.0, -radius * math.cos(ang)])
-    fwd = -eye / np.linalg.norm(eye)
-    up = np.array([0.0, -1.0, 0.0])  # image y points down
-    right = np.cross(up, fwd)
+def look_at_camera(W, H, eye, target, fov_deg=50.0):
+    """Camera at `eye` looking at `target`, image y pointing down (-world y is up)."""
+    eye, target = np.asarray(eye, np.float64), np.asarray(target, np.float64)
+    fwd = target - eye
+    fwd /= np.linalg.norm(fwd)
+    down_hint = np.array([0.0, 1.0, 0.0])  # camera y (image down) = world +y, as in the identity camera
+    right = np.cross(down_hint, fwd)
     right /= np.linalg.norm(right)
     down = np.cross(fwd, right)
     Rc2w = np.stack([right, down, fwd], axis=1)  # columns = camera axes in world
     Tw2c = -Rc2w.T @ eye
     return make_camera(W, H, fov_deg, R=Rc2w, T=Tw2c)
+
+
+def ring_camera(W, H, k, n, radius=3.0, fov_deg=50.0):
+    """k-th of n cameras on a horizontal ring of `radius` looking at the origin (config 4 views)."""
+    ang = 2.0 * math.pi * k / n
+    return look_at_camera(W, H, [radius * math.sin(ang), 0.0, -radius * math.cos(ang)], [0.0, 0.0, 0.0], fov_deg)
+
+
+def orbit_camera(W, H, yaw_deg, center=(0.0, 0.0, 3.5), fov_deg=50.0):
+    """Camera orbiting `center` at the distance of the origin, yaw 0 = the identity view of the S-uniform scene."""
+    c = np.asarray(center, np.float64)
+    d = np.linalg.norm(c)
+    a = math.radians(yaw_deg)
+    eye = c + d * np.array([-math.sin(a), 0.0, -math.cos(a)])
+    return look_at_camera(W, H, eye, c, fov_deg)

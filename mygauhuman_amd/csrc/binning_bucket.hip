@@ -29,9 +29,24 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_count_kernel(const GeomState
 }
 
 // exclusive scan of counts[tiles] -> ranges[t] = (start, end); cursor[t] = start
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n) {
+// If the instance total exceeds `capacity` (only possible when the host sized the buffer without knowing R) every
+// range is emptied -- nothing is scattered, sorted or blended -- and status[1] is raised for the host to see.
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n,
+                                                          const uint32_t *total, uint32_t capacity, uint32_t *status) {
   __shared__ uint32_t wtot[1024 / WAVE];
   __shared__ uint32_t carry_s;
+  const uint32_t R = *total;
+  if (threadIdx.x == 0 && status) {
+    status[0] = R;
+    status[1] = R > capacity ? 1u : 0u;
+  }
+  if (R > capacity) {
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      cursor[i] = 0;
+      ranges[i] = make_uint2(0u, 0u);
+    }
+    return;
+  }
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
@@ -57,7 +72,8 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *count
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
-                                                                  uint32_t *cursor, uint64_t *bucket) {
+                                                                  uint32_t *cursor, uint64_t *bucket, uint32_t capacity) {
+  if (*g.total > capacity) return;  // overflow: see bucket_scan_kernel
   expand_block_instances(g, radii, P, gx, gy, false, [&](uint32_t, uint32_t gid, uint32_t tile, uint32_t dbits) {
     const uint32_t slot = atomicAdd(&cursor[tile], 1u);
     bucket[slot] = ((uint64_t)dbits << 32) | (uint64_t)gid;
@@ -154,8 +170,8 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
   }
 }
 
-int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t R, BinningState &b,
-                   uint2 *ranges, hipStream_t stream, int debug) {
+int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
+                   BinningState &b, uint2 *ranges, uint32_t *dev_status, hipStream_t stream, int debug) {
   const size_t tiles = (size_t)grid_x * grid_y;
   if (grid_x >= 1024 || grid_y >= 1024) {
     set_error("image larger than 16368 px per side is not supported by the packed tile rect");
@@ -169,11 +185,13 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   hipLaunchKernelGGL(bucket_count_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
                      b.tile_counts);
   GSR_LAUNCH_CHECK(stream, debug);
-  hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles);
+  const uint32_t cap32 = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+  hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
+                     g.total, cap32, dev_status);
   GSR_LAUNCH_CHECK(stream, debug);
-  if (R == 0) return GSR_OK;
+  if (!device_sized && capacity == 0) return GSR_OK;
   hipLaunchKernelGGL(bucket_scatter_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
-                     b.tile_cursor, b.keys_a);
+                     b.tile_cursor, b.keys_a, cap32);
   GSR_LAUNCH_CHECK(stream, debug);
   hipLaunchKernelGGL((bucket_sort_kernel<SORT_SMALL, 0, false>), dim3((unsigned)tiles), dim3(256), 0, stream, ranges, b.keys_a,
                      b.vals_s, b.keys_s);

@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "gsr_common.h"
 
@@ -54,6 +56,51 @@ static int readback_u32(const uint32_t *dev, uint32_t *out, hipStream_t stream) 
   return GSR_OK;
 }
 
+// ---- per-stage event timing --------------------------------------------------------------------
+struct ProfRec {
+  int stage;
+  hipEvent_t e0, e1;
+};
+static unsigned g_prof_mask = 0;
+static std::vector<ProfRec> g_prof_recs;           // recorded pairs awaiting collection
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;  // recycled events
+static double g_prof_ms[PROF_NSTAGES];
+static long g_prof_n[PROF_NSTAGES];
+
+void prof_begin(int stage, hipStream_t stream) {
+  if (!(g_prof_mask & (1u << stage))) return;
+  ProfRec r;
+  r.stage = stage;
+  if (!g_prof_pool.empty()) {
+    r.e0 = g_prof_pool.back().first;
+    r.e1 = g_prof_pool.back().second;
+    g_prof_pool.pop_back();
+  } else {
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  }
+  (void)hipEventRecord(r.e0, stream);
+  g_prof_recs.push_back(r);
+}
+void prof_end(int stage, hipStream_t stream) {
+  if (!(g_prof_mask & (1u << stage))) return;
+  for (size_t i = g_prof_recs.size(); i-- > 0;)
+    if (g_prof_recs[i].stage == stage) {
+      (void)hipEventRecord(g_prof_recs[i].e1, stream);
+      return;
+    }
+}
+static void prof_collect() {
+  for (auto &r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      g_prof_ms[r.stage] += ms;
+      g_prof_n[r.stage] += 1;
+    }
+    g_prof_pool.emplace_back(r.e0, r.e1);
+  }
+  g_prof_recs.clear();
+}
+
 int set_blend_forward_waves(int nw);
 int set_blend_backward_waves(int nw);
 
@@ -77,6 +124,30 @@ int gsr_set_binning_mode(int mode) {
 }
 int gsr_get_binning_mode(void) { return g_binning_mode; }
 
+int gsr_profile_enable(unsigned stage_mask) {
+  prof_collect();
+  g_prof_mask = stage_mask & ((1u << PROF_NSTAGES) - 1);
+  return GSR_OK;
+}
+int gsr_profile_reset(void) {
+  prof_collect();
+  for (int i = 0; i < PROF_NSTAGES; i++) {
+    g_prof_ms[i] = 0.0;
+    g_prof_n[i] = 0;
+  }
+  return GSR_OK;
+}
+int gsr_profile_read(int stage, double *total_ms, long *launches) {
+  if (stage < 0 || stage >= PROF_NSTAGES || !total_ms || !launches) {
+    set_error("gsr_profile_read: bad arguments");
+    return GSR_EINVAL;
+  }
+  prof_collect();
+  *total_ms = g_prof_ms[stage];
+  *launches = g_prof_n[stage];
+  return GSR_OK;
+}
+
 int gsr_set_tuning(const char *key, int value) {
   if (!key) return GSR_EINVAL;
   if (!strcmp(key, "blend_fwd_waves")) return set_blend_forward_waves(value);
@@ -99,6 +170,146 @@ int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const
   return GSR_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+struct FwdIn {
+  int P, D, M, width, height, prefiltered, debug;
+  const float *background, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp, *viewmatrix,
+      *projmatrix, *cam_pos;
+  float scale_modifier, tan_fovx, tan_fovy;
+  float *out_color, *out_depth, *out_alpha;
+  int *radii;
+};
+
+int validate_forward(const FwdIn &in, const char *who) {
+  if (in.P < 0 || in.width <= 0 || in.height <= 0) {
+    set_error("%s: bad sizes", who);
+    return GSR_EINVAL;
+  }
+  if (in.P == 0) return GSR_OK;
+  if (!in.background || !in.means3D || !in.opacities || !in.viewmatrix || !in.projmatrix || !in.cam_pos || !in.out_color ||
+      !in.out_depth || !in.out_alpha) {
+    set_error("%s: null required pointer", who);
+    return GSR_EINVAL;
+  }
+  if (!in.colors_precomp && !in.shs) {  // CR/rasterizer_impl.cu:244-247 (NUM_CHANNELS == 3 here, so SHs are acceptable)
+    set_error("%s: provide SHs or precomputed colours", who);
+    return GSR_EINVAL;
+  }
+  if (!in.cov3D_precomp && (!in.scales || !in.rotations)) {
+    set_error("%s: provide scales+rotations or a precomputed 3D covariance", who);
+    return GSR_EINVAL;
+  }
+  if (!in.colors_precomp && (in.D < 0 || in.D > 3 || in.M < (in.D + 1) * (in.D + 1))) {
+    set_error("%s: SH degree %d needs M >= %d coefficients (got %d)", who, in.D, (in.D + 1) * (in.D + 1), in.M);
+    return GSR_EINVAL;
+  }
+  return GSR_OK;
+}
+
+// preprocess + device-wide scan of tiles_touched
+int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStream_t stream) {
+  const int grid_x = (in.width + TILE - 1) / TILE, grid_y = (in.height + TILE - 1) / TILE;
+  PreprocessArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.P = in.P;
+  pa.D = in.D;
+  pa.M = in.M;
+  pa.means3D = in.means3D;
+  pa.scales = in.scales;
+  pa.rotations = in.rotations;
+  pa.opacities = in.opacities;
+  pa.shs = in.shs;
+  pa.cov3D_precomp = in.cov3D_precomp;
+  pa.colors_precomp = in.colors_precomp;
+  pa.scale_modifier = in.scale_modifier;
+  pa.view = in.viewmatrix;
+  pa.proj = in.projmatrix;
+  pa.campos = in.cam_pos;
+  pa.W = in.width;
+  pa.H = in.height;
+  pa.grid_x = grid_x;
+  pa.grid_y = grid_y;
+  pa.tan_fovx = in.tan_fovx;
+  pa.tan_fovy = in.tan_fovy;
+  pa.focal_y = in.height / (2.0f * in.tan_fovy);  // CR/rasterizer_impl.cu:224-225
+  pa.focal_x = in.width / (2.0f * in.tan_fovx);
+  pa.radii = radii;
+  pa.geom = geom;
+  pa.prefiltered = in.prefiltered;
+  prof_begin(PROF_PREPROCESS_FWD, stream);
+  int rc = launch_preprocess_forward(pa, stream);
+  prof_end(PROF_PREPROCESS_FWD, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, in.debug);
+  prof_begin(PROF_SCAN, stream);
+  rc = launch_scan_block_sums(geom, in.P, stream);
+  prof_end(PROF_SCAN, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, in.debug);
+  return GSR_OK;
+}
+
+// binning + blend.  capacity = number of instances the binning buffer can hold; R_host < 0 means "unknown on the
+// host" (asynchronous mode: tile-bucket back-end, kernels read R from geom.total and honour `capacity`).
+int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, const ImageState &img, const int *radii,
+                    long R_host, size_t capacity, uint32_t *dev_status, hipStream_t stream) {
+  const int grid_x = (in.width + TILE - 1) / TILE, grid_y = (in.height + TILE - 1) / TILE;
+  const size_t tiles = (size_t)grid_x * grid_y;
+  int rc;
+  prof_begin(PROF_BINNING, stream);
+  if (R_host < 0 || g_binning_mode == GSR_BINNING_TILE_BUCKET) {
+    rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, dev_status, stream, in.debug);
+    if (rc != GSR_OK) return rc;
+  } else {
+    const size_t R = (size_t)R_host;
+    const int end_bit = 32 + (int)higher_msb((uint32_t)tiles);  // CR/rasterizer_impl.cu:302,310
+    const int passes = radix_passes(end_bit);
+    // duplicate into whichever buffer makes the last pass land in (keys_s, vals_s)
+    uint64_t *dup_k = (passes % 2) ? bin.keys_a : bin.keys_s;
+    uint32_t *dup_v = (passes % 2) ? bin.vals_a : bin.vals_s;
+    uint64_t *oth_k = (passes % 2) ? bin.keys_s : bin.keys_a;
+    uint32_t *oth_v = (passes % 2) ? bin.vals_s : bin.vals_a;
+    rc = launch_duplicate(geom, radii, in.P, grid_x, grid_y, dup_k, dup_v, stream);
+    if (rc != GSR_OK) return rc;
+    GSR_LAUNCH_CHECK(stream, in.debug);
+    rc = radix_sort_u64(R, dup_k, dup_v, oth_k, oth_v, dup_k, dup_v, end_bit, bin.hist, stream, in.debug);
+    if (rc != GSR_OK) return rc;
+    rc = launch_tile_ranges(R, bin.keys_s, img.ranges, tiles, stream);
+    if (rc != GSR_OK) return rc;
+    GSR_LAUNCH_CHECK(stream, in.debug);
+  }
+  prof_end(PROF_BINNING, stream);
+
+  BlendFwdArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.ranges = img.ranges;
+  fa.point_list = bin.vals_s;
+  fa.recs = geom.recs;
+  fa.W = in.width;
+  fa.H = in.height;
+  fa.grid_x = grid_x;
+  fa.grid_y = grid_y;
+  fa.bg = in.background;
+  fa.out_color = in.out_color;
+  fa.out_depth = in.out_depth;
+  fa.out_alpha = in.out_alpha;
+  fa.final_T = img.final_T;
+  fa.n_contrib = img.n_contrib;
+  prof_begin(PROF_BLEND_FWD, stream);
+  rc = launch_blend_forward(fa, stream);
+  prof_end(PROF_BLEND_FWD, stream);
+  if (rc != GSR_OK) return rc;
+  GSR_LAUNCH_CHECK(stream, in.debug);
+  return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
                           gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
                           int height, const float *means3D, const float *shs, const float *colors_precomp,
@@ -108,28 +319,16 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
                           int *radii, int debug, int *host_num_rendered, gsr_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (host_num_rendered) *host_num_rendered = 0;
-  if (P < 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc || !host_num_rendered) {
-    set_error("gsr_rasterize_forward: bad sizes or missing allocation callbacks");
+  if (!geometry_alloc || !binning_alloc || !image_alloc || !host_num_rendered) {
+    set_error("gsr_rasterize_forward: missing allocation callbacks");
     return GSR_EINVAL;
   }
+  const FwdIn in = {P, D, M, width, height, prefiltered, debug, background, means3D, shs, colors_precomp, opacities, scales,
+                    rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, scale_modifier, tan_fovx, tan_fovy, out_color,
+                    out_depth, out_alpha, radii};
+  int rc = validate_forward(in, "gsr_rasterize_forward");
+  if (rc != GSR_OK) return rc;
   if (P == 0) return GSR_OK;  // DGR/rasterize_points.cu:84
-  if (!background || !means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_depth || !out_alpha) {
-    set_error("gsr_rasterize_forward: null required pointer");
-    return GSR_EINVAL;
-  }
-  if (!colors_precomp && !shs) {  // CR/rasterizer_impl.cu:244-247 (NUM_CHANNELS == 3 here, so SHs are acceptable)
-    set_error("gsr_rasterize_forward: provide SHs or precomputed colours");
-    return GSR_EINVAL;
-  }
-  if (!cov3D_precomp && (!scales || !rotations)) {
-    set_error("gsr_rasterize_forward: provide scales+rotations or a precomputed 3D covariance");
-    return GSR_EINVAL;
-  }
-  if (!colors_precomp && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) {
-    set_error("gsr_rasterize_forward: SH degree %d needs M >= %d coefficients (got %d)", D, (D + 1) * (D + 1), M);
-    return GSR_EINVAL;
-  }
-
   const int grid_x = (width + TILE - 1) / TILE, grid_y = (height + TILE - 1) / TILE;
   const size_t tiles = (size_t)grid_x * grid_y, npix = (size_t)width * height;
 
@@ -147,93 +346,57 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
   }
   ImageState img = image_from_chunk(ichunk, npix, tiles);
 
-  PreprocessArgs pa;
-  memset(&pa, 0, sizeof(pa));
-  pa.P = P;
-  pa.D = D;
-  pa.M = M;
-  pa.means3D = means3D;
-  pa.scales = scales;
-  pa.rotations = rotations;
-  pa.opacities = opacities;
-  pa.shs = shs;
-  pa.cov3D_precomp = cov3D_precomp;
-  pa.colors_precomp = colors_precomp;
-  pa.scale_modifier = scale_modifier;
-  pa.view = viewmatrix;
-  pa.proj = projmatrix;
-  pa.campos = cam_pos;
-  pa.W = width;
-  pa.H = height;
-  pa.grid_x = grid_x;
-  pa.grid_y = grid_y;
-  pa.tan_fovx = tan_fovx;
-  pa.tan_fovy = tan_fovy;
-  pa.focal_y = height / (2.0f * tan_fovy);  // CR/rasterizer_impl.cu:224-225
-  pa.focal_x = width / (2.0f * tan_fovx);
-  pa.radii = radii;
-  pa.geom = geom;
-  pa.prefiltered = prefiltered;
-
-  int rc = launch_preprocess_forward(pa, stream);
+  rc = forward_stage_a(in, geom, radii, stream);
   if (rc != GSR_OK) return rc;
-  GSR_LAUNCH_CHECK(stream, debug);
-  rc = launch_scan_block_sums(geom, P, stream);
-  if (rc != GSR_OK) return rc;
-  GSR_LAUNCH_CHECK(stream, debug);
-
-  uint32_t R = 0;
+  uint32_t R = 0;  // the one device -> host read of the call (CR/rasterizer_impl.cu:283)
   rc = readback_u32(geom.total, &R, stream);
   if (rc != GSR_OK) return rc;
   *host_num_rendered = (int)R;
-
   char *bchunk = binning_alloc(binning_user, binning_bytes((size_t)R, tiles));
   if (!bchunk) {
     set_error("binning allocation callback returned null");
     return GSR_ENOMEM;
   }
   BinningState bin = binning_from_chunk(bchunk, (size_t)R, tiles);
+  return forward_stage_b(in, geom, bin, img, radii, (long)R, (size_t)R, nullptr, stream);
+}
 
-  if (g_binning_mode == GSR_BINNING_TILE_BUCKET) {
-    rc = bucket_binning(geom, radii, P, grid_x, grid_y, (size_t)R, bin, img.ranges, stream, debug);
-    if (rc != GSR_OK) return rc;
-  } else {
-    const int end_bit = 32 + (int)higher_msb((uint32_t)tiles);  // CR/rasterizer_impl.cu:302,310
-    const int passes = radix_passes(end_bit);
-    // duplicate into whichever buffer makes the last pass land in (keys_s, vals_s)
-    uint64_t *dup_k = (passes % 2) ? bin.keys_a : bin.keys_s;
-    uint32_t *dup_v = (passes % 2) ? bin.vals_a : bin.vals_s;
-    uint64_t *oth_k = (passes % 2) ? bin.keys_s : bin.keys_a;
-    uint32_t *oth_v = (passes % 2) ? bin.vals_s : bin.vals_a;
-    rc = launch_duplicate(geom, radii, P, grid_x, grid_y, dup_k, dup_v, stream);
-    if (rc != GSR_OK) return rc;
-    GSR_LAUNCH_CHECK(stream, debug);
-    rc = radix_sort_u64((size_t)R, dup_k, dup_v, oth_k, oth_v, dup_k, dup_v, end_bit, bin.hist, stream, debug);
-    if (rc != GSR_OK) return rc;
-    rc = launch_tile_ranges((size_t)R, bin.keys_s, img.ranges, tiles, stream);
-    if (rc != GSR_OK) return rc;
-    GSR_LAUNCH_CHECK(stream, debug);
-  }
+size_t gsr_geometry_bytes(int P) { return geom_bytes(P > 0 ? (size_t)P : 1); }
+size_t gsr_image_bytes(int width, int height) {
+  const size_t tiles = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  return image_bytes((size_t)width * height, tiles);
+}
+size_t gsr_binning_bytes(size_t capacity, int width, int height) {
+  const size_t tiles = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  return binning_bytes(capacity, tiles);
+}
 
-  BlendFwdArgs fa;
-  memset(&fa, 0, sizeof(fa));
-  fa.ranges = img.ranges;
-  fa.point_list = bin.vals_s;
-  fa.recs = geom.recs;
-  fa.W = width;
-  fa.H = height;
-  fa.grid_x = grid_x;
-  fa.grid_y = grid_y;
-  fa.bg = background;
-  fa.out_color = out_color;
-  fa.out_depth = out_depth;
-  fa.out_alpha = out_alpha;
-  fa.final_T = img.final_T;
-  fa.n_contrib = img.n_contrib;
-  rc = launch_blend_forward(fa, stream);
+int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
+                                int D, int M, const float *background, int width, int height, const float *means3D,
+                                const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                                float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                                float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                                int *radii, int debug, uint32_t *dev_status, gsr_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const FwdIn in = {P, D, M, width, height, prefiltered, debug, background, means3D, shs, colors_precomp, opacities, scales,
+                    rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, scale_modifier, tan_fovx, tan_fovy, out_color,
+                    out_depth, out_alpha, radii};
+  int rc = validate_forward(in, "gsr_rasterize_forward_async");
   if (rc != GSR_OK) return rc;
-  GSR_LAUNCH_CHECK(stream, debug);
-  return GSR_OK;
+  if (!geom_buffer || !binning_buffer || !image_buffer || !dev_status || P <= 0) {
+    set_error("gsr_rasterize_forward_async: buffers, dev_status and P > 0 are required");
+    return GSR_EINVAL;
+  }
+  const int grid_x = (width + TILE - 1) / TILE, grid_y = (height + TILE - 1) / TILE;
+  const size_t tiles = (size_t)grid_x * grid_y, npix = (size_t)width * height;
+  GeomState geom = geom_from_chunk(geom_buffer, (size_t)P);
+  if (!radii) radii = geom.internal_radii;
+  ImageState img = image_from_chunk(image_buffer, npix, tiles);
+  BinningState bin = binning_from_chunk(binning_buffer, binning_capacity, tiles);
+  rc = forward_stage_a(in, geom, radii, stream);
+  if (rc != GSR_OK) return rc;
+  return forward_stage_b(in, geom, bin, img, radii, -1, binning_capacity, dev_status, stream);
 }
 
 int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
@@ -285,7 +448,9 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
   ba.dL_ddepth = dL_ddepths;
   ba.dL_dalpha = dL_dalphas;
   ba.grad_rows = geom.grad_rows;
+  prof_begin(PROF_BLEND_BWD, stream);
   int rc = launch_blend_backward(ba, stream);
+  prof_end(PROF_BLEND_BWD, stream);
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, debug);
 
@@ -322,7 +487,9 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
   pb.dL_dsh = dL_dsh;
   pb.dL_dscale = dL_dscale;
   pb.dL_drot = dL_drot;
+  prof_begin(PROF_PREPROCESS_BWD, stream);
   rc = launch_preprocess_backward(pb, stream);
+  prof_end(PROF_PREPROCESS_BWD, stream);
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;

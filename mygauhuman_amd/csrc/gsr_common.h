@@ -135,6 +135,13 @@ int check_hip(hipError_t e, const char *what, const char *file, int line);
     if (debug) GSR_HIP(hipStreamSynchronize(stream));                        \
   } while (0)
 
+// ---- optional per-stage HIP-event timing (gsr_api.hip): bench.py brackets the dominant kernel with events on the
+// launch stream inside its timed region.  Disabled (zero cost) unless gsr_profile_enable() selected the stage.
+enum ProfStage { PROF_PREPROCESS_FWD = 0, PROF_SCAN = 1, PROF_BINNING = 2, PROF_BLEND_FWD = 3, PROF_BLEND_BWD = 4,
+                 PROF_PREPROCESS_BWD = 5, PROF_NSTAGES = 6 };
+void prof_begin(int stage, hipStream_t stream);
+void prof_end(int stage, hipStream_t stream);
+
 // ---- kernel launchers (one translation unit each) ---------------------------------------------
 struct PreprocessArgs {
   int P, D, M;
@@ -203,8 +210,10 @@ int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream);
 int launch_query_recs(int what, int P, const GeomState &g, void *dst, hipStream_t stream);
 
 // tile-bucket binning (binning_bucket.hip)
-int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t R, BinningState &b,
-                   uint2 *ranges, hipStream_t stream, int debug);
+// capacity = instances the binning buffer holds.  device_sized: the host does not know R; the kernels read it from
+// g.total, write dev_status[0] = R, dev_status[1] = (R > capacity) and render nothing on overflow.
+int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
+                   BinningState &b, uint2 *ranges, uint32_t *dev_status, hipStream_t stream, int debug);
 
 }  // namespace gsr
 

@@ -79,8 +79,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,
-                                 debug):
-    """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207)."""
+                                 debug, out=None):
+    """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207).
+
+    `out` (extension, keyword only in practice): dict name -> preallocated contiguous float32 tensor for any of
+    means3D / sh / opacity / scales / rotations / cov3D / colors / means2D; the view-parallel trainer passes views of
+    one flat all-reduce bucket so gradients are produced in place."""
     dev = means3D.device
     P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
@@ -88,15 +92,25 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     # the backward-preprocess kernel writes every element of the tensors it owns (zeros for culled Gaussians)
     new = torch.zeros if P == 0 else torch.empty
     has_sr = scales.numel() != 0
-    dL_dmeans3D = new((P, 3), **opts)
-    dL_dmeans2D = new((P, 3), **opts)
-    dL_dcolors = new((P, 3), **opts)
+    out = out or {}
+
+    def _get(name, shape, alloc):
+        t = out.get(name)
+        if t is None:
+            return alloc(shape, **opts)
+        if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError(f"out['{name}'] must be a contiguous float32 tensor of shape {tuple(shape)} on {dev}")
+        return t
+
+    dL_dmeans3D = _get("means3D", (P, 3), new)
+    dL_dmeans2D = _get("means2D", (P, 3), new)
+    dL_dcolors = _get("colors", (P, 3), new)
     dL_dconic = new((P, 2, 2), **opts)
-    dL_dopacity = new((P, 1), **opts)
-    dL_dcov3D = new((P, 6), **opts)
-    dL_dsh = new((P, M, 3), **opts)
-    dL_dscales = (new if has_sr else torch.zeros)((P, 3), **opts)
-    dL_drotations = (new if has_sr else torch.zeros)((P, 4), **opts)
+    dL_dopacity = _get("opacity", (P, 1), new)
+    dL_dcov3D = _get("cov3D", (P, 6), new)
+    dL_dsh = _get("sh", (P, M, 3), new)
+    dL_dscales = _get("scales", (P, 3), new if has_sr else torch.zeros)
+    dL_drotations = _get("rotations", (P, 4), new if has_sr else torch.zeros)
     if P != 0:
         means3D, colors = _f32c(means3D, "means3D"), _f32c(colors, "colors")
         scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")

@@ -173,3 +173,45 @@ def test_operator_api_autograd(oracle):
     util.assert_close("rotations.grad", t["rotations"].grad.cpu().numpy(), want["dL_drotations"], max_bad_frac=2e-4)
     np.testing.assert_array_equal(radii.cpu().numpy(), ref["pre"]["radii"])
     assert rast.markVisible(t["means3D"].detach()).all()
+
+
+def test_async_session_matches_sync_path_and_reports_overflow(oracle):
+    """RasterSession (sync-free forward, fused loss gradient, in-place backward) == the reference-shaped bindings."""
+    from mygauhuman_amd import parallel
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    from mygauhuman_amd.fastpath import RasterSession
+    P, W, H = 6000, 144, 80
+    cam, g = util.make_scene(P, W, H, 8, 3)
+    bg = util.to_dev(np.array([0.2, 0.1, 0.4], np.float32))
+    params = dict(means3D=util.to_dev(g["means3D"]), shs=util.to_dev(g["shs"]), opacities=util.to_dev(g["opacities"]),
+                  scales=util.to_dev(g["scales"]), rotations=util.to_dev(g["rotations"]))
+    camd = dict(cam, viewmatrix=util.to_dev(cam["viewmatrix"]), projmatrix=util.to_dev(cam["projmatrix"]),
+                campos=util.to_dev(cam["campos"]))
+    rng = np.random.default_rng(2)
+    gt = util.to_dev(rng.uniform(0, 1, (3, H, W)).astype(np.float32))
+    mask = util.to_dev((rng.uniform(0, 1, (1, H, W)) > 0.5).astype(np.float32))
+    step = parallel.ViewParallelStep(params, 3, camd, bg)
+    color, alpha, radii = step(camd, bg, gt, mask, reduce=False)
+    assert not step.session.overflowed()
+    e = torch.empty(0)
+    R, c2, d2, a2, r2, gb, bb, ib = _C.rasterize_gaussians(bg, params["means3D"], e, params["opacities"], params["scales"],
+                                                           params["rotations"], 1.0, e, camd["viewmatrix"], camd["projmatrix"],
+                                                           cam["tanfovx"], cam["tanfovy"], H, W, params["shs"], 3,
+                                                           camd["campos"], False, False)
+    assert step.session.num_rendered() == R
+    assert torch.equal(color, c2) and torch.equal(alpha, a2) and torch.equal(radii, r2)
+    dc = torch.sign(c2 - gt) / c2.numel()
+    da = 0.2 * (a2 - mask) / a2.numel()
+    np.testing.assert_allclose(step.session.dL_dcolor.cpu().numpy(), dc.cpu().numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(step.session.dL_dalpha.cpu().numpy(), da.cpu().numpy(), rtol=1e-6, atol=1e-12)
+    grads = _C.rasterize_gaussians_backward(bg, params["means3D"], r2, e, params["scales"], params["rotations"], 1.0, e,
+                                            camd["viewmatrix"], camd["projmatrix"], cam["tanfovx"], cam["tanfovy"], dc,
+                                            torch.zeros_like(a2), da, params["shs"], 3, camd["campos"], gb, R, bb, ib, a2, False)
+    b = step.bucket
+    for name, ref in (("means3D", grads[3]), ("sh", grads[5]), ("opacity", grads[2]), ("scales", grads[6]), ("rotations", grads[7])):
+        util.assert_close(name, b[name].cpu().numpy(), ref.cpu().numpy(), tol=2e-5, max_bad_frac=1e-4)
+    # a session that is too small reports overflow and renders only the background
+    small = RasterSession(P, W, H, 16, "cuda", capacity=max(1, R // 3))
+    col, _, _, _ = small.forward(params, camd, bg, 3)
+    assert small.overflowed() and small.num_rendered() == R
+    np.testing.assert_array_equal(col.cpu().numpy(), np.broadcast_to(bg.cpu().numpy()[:, None, None], (3, H, W)))
