@@ -4,12 +4,14 @@
 // (tile << 32 | depth bits): 6 passes over 12-byte pairs for a 45-bit key (CR/rasterizer_impl.cu:291-320).  The sorted
 // order only ever matters INSIDE a tile, and the per-tile lists are short (hundreds of entries), which is LDS-sized
 // work on MI355X.  So this back-end never sorts globally:
-//   1. count   : every instance increments its tile's counter                  (integer atomics, load-balanced)
+//   1. count   : every instance increments its tile's counter with ONE returning atomic and keeps the returned
+//                arrival rank                                                   (load-balanced over instances)
 //   2. scan    : exclusive scan of the tile counters -> ranges[tile] directly   (replaces identifyTileRanges)
-//   3. scatter : every instance takes a slot in its tile's bucket (returning atomic) and stores the 64-bit sort key
-//                (depth bits << 32 | Gaussian id) there -- arrival order is arbitrary
-//   4. sort    : one workgroup per tile bitonic-sorts its bucket in LDS and writes the point list (+ the sorted
-//                reference keys).  Keys are unique because they contain the Gaussian id, and ordering by
+//   3. scatter : instance -> bucket[start[tile] + rank] = 64-bit sort key (depth bits << 32 | Gaussian id); no
+//                atomics, arrival order is arbitrary
+//   4. sort    : one WAVE per tile bitonic-sorts lists of up to 1024 keys entirely in registers (lane shuffles, no LDS,
+//                no barriers); longer lists get one workgroup and an LDS bitonic sort.  Both write the point list
+//                (+ the sorted reference keys).  Keys are unique because they contain the Gaussian id, and ordering by
 //                (depth bits, Gaussian id) is exactly what a STABLE sort by (tile, depth bits) gives within a tile,
 //                since the reference emits instances in Gaussian-index order.  Tiles whose list does not fit LDS
 //                (> 8192 entries) are sorted by the same workgroup as LDS-sized runs merged in global memory.
@@ -20,12 +22,19 @@
 
 namespace gsr {
 
-constexpr int SORT_SMALL = 1024, SORT_BIG = 8192;  // LDS capacities (keys) of the two sort launches
+constexpr int SORT_BIG = 8192;  // LDS capacity (keys) of the workgroup sort used for lists > 1024
 
+// One returning atomic per instance: the value it returns is the instance's arrival rank inside its tile, kept in
+// rank[instance] so that the scatter pass needs no second round of atomics.  Counter t lives at counts[t * CSTRIDE]:
+// device-scope atomics execute at the memory side and serialise per 64-byte line, so neighbouring tiles should not
+// share a line.
+constexpr int CSTRIDE = 16;
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_count_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
-                                                                uint32_t *counts) {
-  expand_block_instances(g, radii, P, gx, gy, true,
-                         [&](uint32_t, uint32_t, uint32_t tile, uint32_t) { atomicAdd(&counts[tile], 1u); });
+                                                                uint32_t *counts, uint32_t *rank, uint32_t capacity) {
+  expand_block_instances(g, radii, P, gx, gy, true, [&](uint32_t inst, uint32_t, uint32_t tile, uint32_t) {
+    const uint32_t r = atomicAdd(&counts[(size_t)tile * CSTRIDE], 1u);
+    if (inst < capacity) rank[inst] = r;
+  });
 }
 
 // exclusive scan of counts[tiles] -> ranges[t] = (start, end); cursor[t] = start
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *count
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
     const int i = base + threadIdx.x;
-    const uint32_t v = i < n ? counts[i] : 0;
+    const uint32_t v = i < n ? counts[(size_t)i * CSTRIDE] : 0;
     const uint32_t incl_w = wave_incl_scan(v);
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     if (lane == WAVE - 1) wtot[wave] = incl_w;
@@ -72,11 +81,11 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *count
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
-                                                                  uint32_t *cursor, uint64_t *bucket, uint32_t capacity) {
+                                                                  const uint32_t *start, const uint32_t *rank,
+                                                                  uint64_t *bucket, uint32_t capacity) {
   if (*g.total > capacity) return;  // overflow: see bucket_scan_kernel
-  expand_block_instances(g, radii, P, gx, gy, false, [&](uint32_t, uint32_t gid, uint32_t tile, uint32_t dbits) {
-    const uint32_t slot = atomicAdd(&cursor[tile], 1u);
-    bucket[slot] = ((uint64_t)dbits << 32) | (uint64_t)gid;
+  expand_block_instances(g, radii, P, gx, gy, false, [&](uint32_t inst, uint32_t gid, uint32_t tile, uint32_t dbits) {
+    bucket[start[tile] + rank[inst]] = ((uint64_t)dbits << 32) | (uint64_t)gid;
   });
 }
 
@@ -97,6 +106,88 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr keys, int npow2) {
       __syncthreads();
     }
   }
+}
+
+// ---- wave-level register bitonic sort: lists of up to 64 * NREG keys, one wave per tile, no LDS, no barriers ----
+// Element i of the list lives in register i / 64 of lane i % 64.  A compare-exchange at distance j >= 64 pairs two
+// registers of the same lane; at distance j < 64 it pairs lane l with lane l ^ j of the same register (two
+// ds_bpermute per 64-bit key).  The direction of a pair depends on bit k of the element index.
+template <int NREG>
+__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&key)[NREG], uint32_t lane) {
+  constexpr int N = NREG * WAVE;
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= WAVE) {
+        const int jr = j / WAVE;
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+          if ((r & jr) == 0) {
+            const bool asc = (((r * WAVE) & k) == 0);  // k >= 128 here: decided by the register index alone
+            const uint64_t a = key[r], c = key[r | jr];
+            const bool sw = (a > c) == asc;
+            key[r] = sw ? c : a;
+            key[r | jr] = sw ? a : c;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < NREG; r++) {
+          const uint32_t i = (uint32_t)r * WAVE + lane;
+          const uint64_t mine = key[r];
+          const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine, j, WAVE);
+          const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), j, WAVE);
+          const uint64_t other = ((uint64_t)hi << 32) | lo;
+          const bool lower = (lane & (uint32_t)j) == 0;
+          const bool asc = (i & (uint32_t)k) == 0;
+          const bool take_min = lower == asc;
+          key[r] = take_min ? (mine < other ? mine : other) : (mine > other ? mine : other);
+        }
+      }
+    }
+  }
+}
+
+template <int NREG>
+__device__ __forceinline__ void wave_sort_tile(const uint64_t *b, int n, uint32_t tile, uint32_t base, uint32_t *point_list,
+                                               uint64_t *keys_sorted, uint32_t lane) {
+  uint64_t key[NREG];
+#pragma unroll
+  for (int r = 0; r < NREG; r++) {
+    const int i = r * WAVE + (int)lane;
+    key[r] = i < n ? b[i] : ~0ull;
+  }
+  wave_bitonic_sort<NREG>(key, lane);
+#pragma unroll
+  for (int r = 0; r < NREG; r++) {
+    const int i = r * WAVE + (int)lane;
+    if (i < n) {
+      point_list[base + i] = (uint32_t)key[r];
+      keys_sorted[base + i] = ((uint64_t)tile << 32) | (key[r] >> 32);
+    }
+  }
+}
+
+constexpr int SORT_WAVE_MAX = 1024;  // longest list handled by the register sort (16 keys per lane)
+
+__global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ranges, const uint64_t *bucket, uint32_t *point_list,
+                                                               uint64_t *keys_sorted) {
+  const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+  const uint2 r = ranges[tile];
+  const int n = (int)(r.y - r.x);
+  if (n == 0 || n > SORT_WAVE_MAX) return;
+  const uint64_t *b = bucket + r.x;
+  if (n <= 64)
+    wave_sort_tile<1>(b, n, tile, r.x, point_list, keys_sorted, lane);
+  else if (n <= 128)
+    wave_sort_tile<2>(b, n, tile, r.x, point_list, keys_sorted, lane);
+  else if (n <= 256)
+    wave_sort_tile<4>(b, n, tile, r.x, point_list, keys_sorted, lane);
+  else if (n <= 512)
+    wave_sort_tile<8>(b, n, tile, r.x, point_list, keys_sorted, lane);
+  else
+    wave_sort_tile<16>(b, n, tile, r.x, point_list, keys_sorted, lane);
 }
 
 // CAP = LDS capacity in keys; the instantiation handles tiles with LO < n <= CAP (the big one also n > CAP).  Two
@@ -181,22 +272,22 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     set_error("binning buffer was not sized for the tile-bucket back-end");
     return GSR_EINVAL;
   }
-  GSR_HIP(hipMemsetAsync(b.tile_counts, 0, tiles * sizeof(uint32_t), stream));
-  hipLaunchKernelGGL(bucket_count_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
-                     b.tile_counts);
-  GSR_LAUNCH_CHECK(stream, debug);
   const uint32_t cap32 = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+  GSR_HIP(hipMemsetAsync(b.tile_counts, 0, tiles * CSTRIDE * sizeof(uint32_t), stream));
+  // instance ranks live in the (otherwise unused in this back-end) vals_a array
+  hipLaunchKernelGGL(bucket_count_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
+                     b.tile_counts, b.vals_a, cap32);
+  GSR_LAUNCH_CHECK(stream, debug);
   hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
                      g.total, cap32, dev_status);
   GSR_LAUNCH_CHECK(stream, debug);
   if (!device_sized && capacity == 0) return GSR_OK;
   hipLaunchKernelGGL(bucket_scatter_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
-                     b.tile_cursor, b.keys_a, cap32);
+                     b.tile_cursor, b.vals_a, b.keys_a, cap32);
   GSR_LAUNCH_CHECK(stream, debug);
-  hipLaunchKernelGGL((bucket_sort_kernel<SORT_SMALL, 0, false>), dim3((unsigned)tiles), dim3(256), 0, stream, ranges, b.keys_a,
-                     b.vals_s, b.keys_s);
+  hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, stream, ranges, b.keys_a, b.vals_s, b.keys_s);
   GSR_LAUNCH_CHECK(stream, debug);
-  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_SMALL, true>), dim3((unsigned)tiles), dim3(256), 0, stream, ranges,
+  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)tiles), dim3(256), 0, stream, ranges,
                      b.keys_a, b.vals_s, b.keys_s);
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;

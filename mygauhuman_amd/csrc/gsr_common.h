@@ -99,7 +99,7 @@ inline BinningState binning_from_chunk(char *chunk, size_t R, size_t tiles = 0) 
   carve(chunk, b.hist, sort_hist_words(n));
   b.tile_counts = b.tile_cursor = nullptr;
   if (tiles) {
-    carve(chunk, b.tile_counts, tiles);
+    carve(chunk, b.tile_counts, tiles * 16);  // one counter per 64-byte line (binning_bucket.hip CSTRIDE)
     carve(chunk, b.tile_cursor, tiles);
   }
   return b;
