@@ -58,8 +58,8 @@ constexpr int NACC = 9;
 template <int SLOTS>
 __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs a) {
   constexpr int WPT = 4 / SLOTS;
-  __shared__ float4 s0[WAVE];     // x, y, conic_a, conic_b
-  __shared__ float4 s1[WAVE];     // conic_c, opacity, depth, r
+  __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
+  __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
   __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
   __shared__ uint32_t s_id[WAVE + 4];
 
@@ -72,10 +72,14 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   const size_t plane = (size_t)a.H * a.W;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
-  float pxf[SLOTS], pyf[SLOTS], T[SLOTS], Tfin[SLOTS], bgdot[SLOTS];
+  // Per-pixel replay state.  The reference keeps T plus five "colour behind" recurrences (accum_rec[3], depth, alpha)
+  // and their last_* operands (CR/backward.cu:454-468,529-548).  With e_j = c_j . dL_dpix + depth_j dL_ddepth + dL_dalpha
+  // (one scalar per pair) they collapse into ONE suffix sum X = sum_{j behind i} w_j e_j:
+  //   dL_dalpha_i = T_i e_i - (X_i + T_final (bg . dL_dpix)) / (1 - alpha_i),    w_i = alpha_i T_i,
+  // which is the same value (accum_rec_i = X_i / (T_i (1 - alpha_i))) with 16 fewer instructions per hit and 10 fewer
+  // live registers per pixel.
+  float pxf[SLOTS], pyf[SLOTS], T[SLOTS], X[SLOTS], Tb[SLOTS];
   float dpix0[SLOTS], dpix1[SLOTS], dpix2[SLOTS], ddep[SLOTS], dalp[SLOTS];
-  float arec0[SLOTS], arec1[SLOTS], arec2[SLOTS], adep[SLOTS], aalp[SLOTS];
-  float lalpha[SLOTS], lc0[SLOTS], lc1[SLOTS], lc2[SLOTS], ldep[SLOTS];
   int lastc[SLOTS];
   const int q0 = (int)part * SLOTS, q1 = q0 + SLOTS - 1;
   const float rx0 = (float)(tx * TILE + (q0 & 1) * 8), rx1 = (float)(tx * TILE + (q1 & 1) * 8 + 7);
@@ -90,17 +94,15 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     const int p = py * a.W + px;
     pxf[s] = (float)px;
     pyf[s] = (float)py;
-    Tfin[s] = inside ? a.final_T[p] : 0.f;
-    T[s] = Tfin[s];
+    T[s] = inside ? a.final_T[p] : 0.f;
     lastc[s] = inside ? (int)a.n_contrib[p] : 0;
     dpix0[s] = inside ? a.dL_dpix[p] : 0.f;
     dpix1[s] = inside ? a.dL_dpix[plane + p] : 0.f;
     dpix2[s] = inside ? a.dL_dpix[2 * plane + p] : 0.f;
     ddep[s] = inside ? a.dL_ddepth[p] : 0.f;
     dalp[s] = inside ? a.dL_dalpha[p] : 0.f;
-    bgdot[s] = bg0 * dpix0[s] + bg1 * dpix1[s] + bg2 * dpix2[s];
-    arec0[s] = arec1[s] = arec2[s] = adep[s] = aalp[s] = 0.f;
-    lalpha[s] = lc0[s] = lc1[s] = lc2[s] = ldep[s] = 0.f;
+    Tb[s] = T[s] * (bg0 * dpix0[s] + bg1 * dpix1[s] + bg2 * dpix2[s]);  // T_final * (bg . dL_dpix)
+    X[s] = 0.f;
     maxlast = max(maxlast, lastc[s]);
   }
 #pragma unroll
@@ -129,8 +131,10 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     if (keep) {
       const int slot = __builtin_popcountll(kmask & lt);
       const float4 r1 = src[1];
-      s0[slot] = r0;
-      s1[slot] = r1;
+      // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
+      constexpr float L2E = 1.4426950408889634f;
+      s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
+      s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
       s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)));
       s_id[slot] = id;
     }
@@ -153,9 +157,8 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
 #pragma unroll
           for (int s = 0; s < SLOTS; s++) {
             const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
-            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-            const float p2 = power * 1.4426950408889634f;
-            const bool pre = (fpos < lastc[s]) && !(power > 0.0f) && (p2 + g2.z >= -0.02f);
+            const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
+            const bool pre = (fpos < lastc[s]) && !(p2 > 0.0f) && (p2 + g2.z >= -0.02f);
             if (__ballot(pre) != 0ull) {
               const float G = __builtin_amdgcn_exp2f(p2);
               const float alpha = fminf(0.99f, g1.y * G);
@@ -163,21 +166,14 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
               if (__ballot(hit) != 0ull) anyhit |= 1u << u;
               if (hit) {  // exec-masked body: state and sums change on hit lanes only
                 const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = T[s] * rc;
-                const float w = alpha * Tn;  // dchannel_dcolor
-                const float one_m_la = 1.f - lalpha[s];
-                arec0[s] = lalpha[s] * lc0[s] + one_m_la * arec0[s];
-                arec1[s] = lalpha[s] * lc1[s] + one_m_la * arec1[s];
-                arec2[s] = lalpha[s] * lc2[s] + one_m_la * arec2[s];
-                adep[s] = lalpha[s] * ldep[s] + one_m_la * adep[s];
-                aalp[s] = lalpha[s] + one_m_la * aalp[s];
-                float dL_dopa = (g1.w - arec0[s]) * dpix0[s] + (g2.x - arec1[s]) * dpix1[s] + (g2.y - arec2[s]) * dpix2[s];
-                dL_dopa += (g1.z - adep[s]) * ddep[s];
-                dL_dopa += (1.f - aalp[s]) * dalp[s];
-                dL_dopa *= Tn;
-                dL_dopa += (-Tfin[s] * rc) * bgdot[s];
+                const float Tn = T[s] * rc;  // transmittance in front of this Gaussian
+                const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
+                const float e = g1.w * dpix0[s] + g2.x * dpix1[s] + g2.y * dpix2[s] + g1.z * ddep[s] + dalp[s];
+                const float dL_dalpha = Tn * e - (X[s] + Tb[s]) * rc;
+                X[s] += w * e;
+                T[s] = Tn;
                 // moments of r = G * dL_dalpha over the pixels; preprocess_bwd.hip turns them into dL_dmean2D / dL_dconic
-                const float r = G * dL_dopa;
+                const float r = G * dL_dalpha;
                 const float rx = r * dx, ry = r * dy;
                 acc[u][0] += rx;
                 acc[u][1] += ry;
@@ -188,12 +184,6 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
                 acc[u][6] += w * dpix0[s];
                 acc[u][7] += w * dpix1[s];
                 acc[u][8] += w * dpix2[s];
-                T[s] = Tn;
-                lalpha[s] = alpha;
-                lc0[s] = g1.w;
-                lc1[s] = g2.x;
-                lc2[s] = g2.y;
-                ldep[s] = g1.z;
               }
             }
           }

@@ -27,8 +27,8 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
 template <int SLOTS>
 __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs a) {
   constexpr int WPT = 4 / SLOTS;  // waves per tile
-  __shared__ float4 s0[WAVE];     // x, y, conic_a, conic_b
-  __shared__ float4 s1[WAVE];     // conic_c, opacity, depth, r
+  __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
+  __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
   __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), list position + 1 (bits)
 
   const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
@@ -85,8 +85,10 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
     if (keep) {
       const int slot = __builtin_popcountll(kmask & lt);
       const float4 r1 = src[1];
-      s0[slot] = r0;
-      s1[slot] = r1;
+      // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
+      constexpr float L2E = 1.4426950408889634f;
+      s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
+      s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
       s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(idx + 1)));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -101,10 +103,9 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
 #pragma unroll
       for (int s = 0; s < SLOTS; s++) {
         const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
-        const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-        const float p2 = power * 1.4426950408889634f;
+        const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
         // cheap necessary condition for alpha >= 1/255:  log2(255*o) + power*log2(e) >= 0  (0.02 safety margin)
-        const bool pre = !done[s] && !(power > 0.0f) && (p2 + g2.z >= -0.02f);
+        const bool pre = !done[s] && !(p2 > 0.0f) && (p2 + g2.z >= -0.02f);
         if (__ballot(pre) != 0ull) {
           const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(p2));
           const bool hit = pre && !(alpha < 1.0f / 255.0f);
