@@ -1,0 +1,161 @@
+"""SMPL linear-blend skinning of the canonical Gaussians -- host side of the LBS row of the hot path.
+
+Mirrors GaussianModel.coarse_deform_c2source and its helpers (scene/gaussian_model.py:768-1013):
+  batch_rodrigues(_torch)            :982-1013, :894-912
+  get_rigid_transformation_torch     :914-944
+  get_transform_params_torch         :947-980
+  coarse_deform_c2source             :768-872   (same arguments / return tuple; `smpl` replaces self.SMPL_NEUTRAL)
+The joint transforms (24 4x4 matrices) and the per-vertex blend-shape offset tables are a few dozen tiny tensor
+ops per frame and stay torch (they carry the autograd graph of the pose-refinement MLP).  Everything per POINT
+(nearest SMPL vertex, weight softmax, 24-way blends, 3x3 inverse, offsets, posing, world transform) is ONE HIP
+kernel forward (gsr_lbs_forward) and ONE backward (gsr_lbs_backward) behind a torch.autograd.Function, instead of
+~40 torch kernels + KNN_CUDA + an autograd graph over [P, 24, 16] intermediates.
+"""
+import torch
+
+from ._lib import check, lib, ptr
+
+
+def batch_rodrigues(rot_vecs):
+    """Axis-angle [N,3] -> rotation matrices [N,3,3]; angle = |v + 1e-8| like the reference."""
+    n = rot_vecs.shape[0]
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos, sin = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros((n, 1), dtype=rot_vecs.dtype, device=rot_vecs.device)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(n, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None]
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def get_rigid_transformation_torch(rot_mats, joints, parents):
+    """rot_mats [bs,24,3,3], joints [bs,24,3], parents [24] -> relative transforms [bs,24,4,4] (rest pose removed)."""
+    bs, nj = joints.shape[:2]
+    rel = joints.clone()
+    rel[:, 1:] = rel[:, 1:] - joints[:, parents[1:]]
+    tm = torch.cat([rot_mats, rel[..., None]], dim=-1)
+    pad = torch.zeros((bs, nj, 1, 4), dtype=rot_mats.dtype, device=rot_mats.device)
+    pad[..., 3] = 1
+    tm = torch.cat([tm, pad], dim=-2)
+    chain = [tm[:, 0]]
+    for i in range(1, nj):
+        chain.append(torch.matmul(chain[int(parents[i])], tm[:, i]))
+    tr = torch.stack(chain, dim=1)
+    jh = torch.cat([joints, torch.zeros((bs, nj, 1), dtype=joints.dtype, device=joints.device)], dim=-1)
+    relj = torch.sum(tr * jh[:, :, None], dim=3)
+    return torch.cat([tr[..., :3], (tr[..., 3] - relj)[..., None]], dim=-1)
+
+
+def get_transform_params_torch(smpl, params, rot_mats=None, correct_Rs=None):
+    v_template, shapedirs, betas = smpl["v_template"], smpl["shapedirs"], params["shapes"]
+    v_shaped = v_template[None] + torch.sum(shapedirs[None][..., :betas.shape[-1]] * betas[:, None], dim=-1).float()
+    if rot_mats is None:
+        poses = params["poses"].reshape(-1, 3)
+        rot_mats = batch_rodrigues(poses).view(params["poses"].shape[0], -1, 3, 3)
+        if correct_Rs is not None:
+            nr = torch.matmul(rot_mats[:, 1:].reshape(-1, 3, 3), correct_Rs.reshape(-1, 3, 3))
+            rot_mats = torch.cat([rot_mats[:, 0:1], nr.reshape(-1, rot_mats.shape[1] - 1, 3, 3)], dim=1)
+    joints = torch.matmul(smpl["J_regressor"][None], v_shaped)
+    parents = smpl["kintree_table"][0]
+    A = get_rigid_transformation_torch(rot_mats, joints, parents)
+    return A, params["R"], params["Th"], joints
+
+
+def pose_offsets(smpl, rot_mats):
+    """(R[1:] - I).flatten() [1,207] @ posedirs^T -> per-vertex offsets [V,3] (gaussian_model.py:805-811,827-839)."""
+    posedirs = smpl["posedirs"]
+    V = smpl["v_template"].shape[0]
+    ident = torch.eye(3, dtype=rot_mats.dtype, device=rot_mats.device)
+    feat = (rot_mats[:, 1:] - ident).reshape(rot_mats.shape[0], -1)
+    return torch.matmul(feat, posedirs.reshape(V * 3, -1).t()).view(-1, V, 3)[0]
+
+
+def shape_offsets(smpl, shapes):
+    sd = smpl["shapedirs"][..., :shapes.shape[-1]]
+    return torch.matmul(sd, shapes.reshape(-1, 1)).squeeze(-1)
+
+
+class _LBSDeform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights):
+        if not query.is_cuda:
+            raise RuntimeError("LBS deform: tensors must live on a HIP device (no CPU path)")
+        dev, f32 = query.device, torch.float32
+        P, V = query.shape[0], smpl_verts.shape[0]
+        c = lambda t: None if t is None else t.detach().contiguous().float()  # noqa: E731
+        query_c, normals_c, loff = c(query), c(normals), c(lbs_offsets)
+        A_big_c, A_pose_c = c(A_big).reshape(24, 16), c(A_pose).reshape(24, 16)
+        ob, os_, op = c(off_big), c(off_shape), c(off_pose)
+        R_c, Th_c, sv, w = c(R).reshape(3, 3), c(Th).reshape(3), c(smpl_verts), c(weights)
+        vert_ids = torch.empty((P,), dtype=torch.int32, device=dev)
+        bweights = torch.empty((P, 24), dtype=f32, device=dev)
+        smpl_pts = torch.empty((P, 3), dtype=f32, device=dev)
+        world_pts = torch.empty((P, 3), dtype=f32, device=dev)
+        transforms = torch.empty((P, 3, 3), dtype=f32, device=dev)
+        translation = torch.empty((P, 3), dtype=f32, device=dev)
+        world_normals = torch.empty((P, 3), dtype=f32, device=dev) if normals is not None else None
+        with torch.cuda.device(dev):
+            check(lib.gsr_lbs_forward(P, V, ptr(query_c), ptr(normals_c), ptr(sv), ptr(w), ptr(loff), ptr(A_big_c), ptr(A_pose_c),
+                                      ptr(ob), ptr(os_), ptr(op), ptr(R_c), ptr(Th_c), ptr(vert_ids), ptr(bweights),
+                                      ptr(smpl_pts), ptr(world_pts), ptr(transforms), ptr(translation), ptr(world_normals),
+                                      torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_forward")
+        ctx.save_for_backward(query_c, normals_c, loff, A_big_c, A_pose_c, ob, os_, op, R_c, vert_ids, w)
+        ctx.shapes = (A_pose.shape, off_pose.shape, V)
+        ctx.mark_non_differentiable(vert_ids, bweights, smpl_pts, translation)
+        return (world_pts, transforms, world_normals if world_normals is not None else torch.empty(0, device=dev), smpl_pts,
+                bweights, translation, vert_ids)
+
+    @staticmethod
+    def backward(ctx, g_world, g_transforms, g_normals, *_unused):
+        query, normals, loff, A_big, A_pose, ob, os_, op, R, vert_ids, w = ctx.saved_tensors
+        A_shape, off_shape_, V = ctx.shapes
+        dev, f32 = query.device, torch.float32
+        P = query.shape[0]
+        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        g_world, g_transforms = c(g_world), c(g_transforms)
+        g_normals = c(g_normals) if (normals is not None and g_normals is not None and g_normals.numel()) else None
+        d_query = torch.empty((P, 3), dtype=f32, device=dev)
+        d_normals = torch.empty((P, 3), dtype=f32, device=dev) if normals is not None else None
+        d_loff = torch.empty((P, 24), dtype=f32, device=dev) if loff is not None else None
+        d_A = torch.zeros((24, 16), dtype=f32, device=dev)
+        d_off = torch.zeros((V, 3), dtype=f32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gsr_lbs_backward(P, V, ptr(query), ptr(normals), ptr(vert_ids), ptr(w), ptr(loff), ptr(A_big), ptr(A_pose),
+                                       ptr(ob), ptr(os_), ptr(op), ptr(R), ptr(g_world), ptr(g_transforms), ptr(g_normals),
+                                       ptr(d_query), ptr(d_normals), ptr(d_loff), ptr(d_A), ptr(d_off),
+                                       torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_backward")
+        return (d_query, d_normals, d_loff, None, d_A.view(A_shape), None, None, d_off.view(off_shape_), None, None, None, None)
+
+
+def lbs_deform(query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights):
+    """Per-point LBS (HIP). Returns dict(world_pts, transforms, world_normals, smpl_pts, bweights, translation, vert_ids)."""
+    o = _LBSDeform.apply(query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights)
+    return dict(world_pts=o[0], transforms=o[1], world_normals=o[2] if normals is not None else None, smpl_pts=o[3],
+                bweights=o[4], translation=o[5], vert_ids=o[6])
+
+
+def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_weights=None, correct_Rs=None,
+                           return_transl=False, normals=None):
+    """Drop-in for GaussianModel.coarse_deform_c2source (batch size 1): same arguments after `smpl`
+    (= self.SMPL_NEUTRAL as device tensors) and the same 6-tuple
+    (smpl_src_pts[1,P,3], world_src_pts[1,P,3], bweights[1,P,24], transforms[1,P,3,3], translation|None, world_normals)."""
+    assert query_pts.shape[0] == 1, "batch size 1 (like every call site of the reference)"
+    # big pose -> T pose
+    A_big, _, _, _ = get_transform_params_torch(smpl, t_params)
+    rot_big = batch_rodrigues(t_params["poses"].view(-1, 3)).view(1, -1, 3, 3)
+    off_big = pose_offsets(smpl, rot_big)
+    off_shape = shape_offsets(smpl, params["shapes"].to(query_pts.device))
+    # T pose -> target pose
+    rot_mats = batch_rodrigues(params["poses"].view(-1, 3)).view(1, -1, 3, 3)
+    if correct_Rs is not None:
+        nr = torch.matmul(rot_mats[:, 1:].reshape(-1, 3, 3), correct_Rs.reshape(-1, 3, 3)).reshape(-1, rot_mats.shape[1] - 1, 3, 3)
+        rot_mats = torch.cat([rot_mats[:, 0:1], nr], dim=1)
+    off_pose = pose_offsets(smpl, rot_mats)
+    A_pose, R, Th, _ = get_transform_params_torch(smpl, params, rot_mats=rot_mats)
+    o = lbs_deform(query_pts[0], None if normals is None else normals[0], None if lbs_weights is None else lbs_weights[0],
+                   A_big[0], A_pose[0], off_big, off_shape, off_pose, R.reshape(3, 3), Th.reshape(-1)[:3], t_vertices[0],
+                   smpl["weights"])
+    translation = o["translation"][None] if return_transl else None
+    wn = None if o["world_normals"] is None else o["world_normals"][None]
+    return o["smpl_pts"][None], o["world_pts"][None], o["bweights"][None], o["transforms"][None], translation, wn

@@ -1,0 +1,144 @@
+"""GPU parity tests of the SMPL LBS kernels: forward against the CPU oracle (oracle/lbs_oracle.c, which is pinned to
+the imported reference smplx.lbs through tests/golden), backward against float64 torch autograd of a restatement of
+the per-point math (the reference relies on autograd for this gradient too).  Tolerance 1e-4 (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], np.int32)
+BIG_POSE = np.zeros(72, np.float32)
+BIG_POSE[5], BIG_POSE[8], BIG_POSE[23], BIG_POSE[26] = np.deg2rad(45), -np.deg2rad(45), -np.deg2rad(30), np.deg2rad(30)
+
+
+def make_smpl(V, seed):
+    rng = np.random.default_rng(seed)
+    vt = rng.uniform(-1, 1, (V, 3)).astype(np.float32) * np.array([0.9, 0.9, 0.15], np.float32)
+    sd = rng.normal(0, 0.01, (V, 3, 10)).astype(np.float32)
+    pd = rng.normal(0, 0.001, (V, 3, 207)).astype(np.float32)  # gaussian_model.py layout [V,3,207]
+    J = rng.uniform(0, 1, (24, V)).astype(np.float32)
+    J /= J.sum(1, keepdims=True)
+    w = rng.uniform(0, 1, (V, 24)).astype(np.float32) ** 4
+    w /= w.sum(1, keepdims=True)
+    return dict(v_template=vt, shapedirs=sd, posedirs=pd, J_regressor=J, weights=w.astype(np.float32), parents=PARENTS)
+
+
+def make_case(oracle, V, P, seed, with_offsets):
+    rng = np.random.default_rng(seed)
+    m = make_smpl(V, seed)
+    betas = rng.normal(0, 1, 10).astype(np.float32)
+    pose = rng.normal(0, 0.2, 72).astype(np.float32)
+    zeros = np.zeros(10, np.float32)
+    rot_big, rot_pose = oracle.rodrigues(BIG_POSE), oracle.rodrigues(pose)
+    A_big, _ = oracle.joint_transforms(m, zeros, rot_big)
+    A_pose, _ = oracle.joint_transforms(m, betas, rot_pose)
+    off_big, off_pose = oracle.pose_offsets(m["posedirs"], rot_big), oracle.pose_offsets(m["posedirs"], rot_pose)
+    off_shape = oracle.shape_offsets(m["shapedirs"], betas)
+    # big-pose vertices = smplx lbs of the template (any vertex cloud works for the nearest-vertex search)
+    big_verts = (m["v_template"] + 0.01 * rng.normal(0, 1, (V, 3))).astype(np.float32)
+    query = (big_verts[rng.integers(0, V, P)] + rng.normal(0, 0.02, (P, 3))).astype(np.float32)
+    normals = rng.normal(0, 1, (P, 3)).astype(np.float32)
+    ang = 0.4
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    Th = np.array([0.1, -0.3, 2.5], np.float32)
+    loff = rng.normal(0, 0.5, (P, 24)).astype(np.float32) if with_offsets else None
+    return dict(m=m, betas=betas, pose=pose, A_big=A_big, A_pose=A_pose, off_big=off_big, off_pose=off_pose,
+                off_shape=off_shape, big_verts=big_verts, query=query, normals=normals, R=R, Th=Th, loff=loff)
+
+
+@pytest.mark.parametrize("V,P", [(700, 1), (700, 1000), (6890, 20000)])
+@pytest.mark.parametrize("with_offsets", [False, True])
+def test_lbs_forward_matches_oracle(oracle, V, P, with_offsets):
+    from mygauhuman_amd import lbs
+    c = make_case(oracle, V, P, V + P, with_offsets)
+    ids = oracle.nearest_vertex(c["query"], c["big_verts"])
+    want = oracle.lbs_deform(c["query"], c["normals"], ids, c["m"]["weights"], c["A_big"], c["A_pose"], c["off_big"],
+                             c["off_shape"], c["off_pose"], c["R"], c["Th"], lbs_off=c["loff"])
+    d = util.to_dev
+    got = lbs.lbs_deform(d(c["query"]), d(c["normals"]), None if c["loff"] is None else d(c["loff"]), d(c["A_big"]),
+                         d(c["A_pose"]), d(c["off_big"]), d(c["off_shape"]), d(c["off_pose"]), d(c["R"]), d(c["Th"]),
+                         d(c["big_verts"]), d(c["m"]["weights"]))
+    np.testing.assert_array_equal(got["vert_ids"].cpu().numpy(), ids)  # index work: bit-exact
+    for k_got, k_want in (("world_pts", "world_src"), ("smpl_pts", "smpl_src"), ("bweights", "bweights"),
+                          ("transforms", "transforms"), ("translation", "translation"), ("world_normals", "world_normals")):
+        np.testing.assert_allclose(got[k_got].cpu().numpy(), want[k_want], rtol=1e-4, atol=1e-4, err_msg=k_got)
+
+
+def test_coarse_deform_c2source_matches_oracle_pipeline(oracle):
+    """The drop-in for GaussianModel.coarse_deform_c2source (torch glue + HIP kernel) against the oracle pieces."""
+    from mygauhuman_amd import lbs
+    V, P = 900, 3000
+    c = make_case(oracle, V, P, 5, True)
+    d = util.to_dev
+    m = c["m"]
+    smpl = dict(v_template=d(m["v_template"]), shapedirs=d(m["shapedirs"]), posedirs=d(m["posedirs"]),
+                J_regressor=d(m["J_regressor"]), weights=d(m["weights"]),
+                kintree_table=torch.from_numpy(np.stack([PARENTS, np.arange(24)]).astype(np.int64)).cuda())
+    params = dict(poses=d(c["pose"][None]), shapes=d(c["betas"][None]), R=d(c["R"]), Th=d(c["Th"][None]))
+    t_params = dict(poses=d(BIG_POSE[None]), shapes=d(np.zeros((1, 10), np.float32)), R=d(np.eye(3, dtype=np.float32)),
+                    Th=d(np.zeros((1, 3), np.float32)))
+    smpl_src, world, bw, tf, transl, wn = lbs.coarse_deform_c2source(
+        smpl, d(c["query"][None]), params, t_params, d(c["big_verts"][None]), lbs_weights=d(c["loff"][None]),
+        return_transl=True, normals=d(c["normals"][None]))
+    ids = oracle.nearest_vertex(c["query"], c["big_verts"])
+    want = oracle.lbs_deform(c["query"], c["normals"], ids, m["weights"], c["A_big"], c["A_pose"], c["off_big"],
+                             c["off_shape"], c["off_pose"], c["R"], c["Th"], lbs_off=c["loff"])
+    assert world.shape == (1, P, 3) and tf.shape == (1, P, 3, 3) and bw.shape == (1, P, 24)
+    np.testing.assert_allclose(world[0].cpu().numpy(), want["world_src"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(tf[0].cpu().numpy(), want["transforms"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(transl[0].cpu().numpy(), want["translation"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(wn[0].cpu().numpy(), want["world_normals"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(smpl_src[0].cpu().numpy(), want["smpl_src"], rtol=1e-4, atol=1e-4)
+
+
+def _torch_deform(query, normals, loff, A_big, A_pose, off_big, off_shape, off_pose, R, Th, ids, weights):
+    """float64 restatement of the per-point math (gaussian_model.py:776-872) for autograd."""
+    bw = weights[ids]
+    if loff is not None:
+        bw = torch.softmax(torch.log(bw + 1e-9) + loff, dim=-1)
+    Ab = (bw @ A_big.reshape(24, 16)).reshape(-1, 4, 4)
+    Ap = (bw @ A_pose.reshape(24, 16)).reshape(-1, 4, 4)
+    Ri = torch.inverse(Ab[:, :3, :3])
+    q = (Ri @ (query - Ab[:, :3, 3])[..., None])[..., 0]
+    n = (Ri @ normals[..., None])[..., 0]
+    q = q - off_big[ids] + off_shape[ids] + off_pose[ids]
+    src = (Ap[:, :3, :3] @ q[..., None])[..., 0] + Ap[:, :3, 3]
+    sn = (Ap[:, :3, :3] @ n[..., None])[..., 0]
+    Rinv = torch.inverse(R)
+    return src @ Rinv + Th, R @ (Ap[:, :3, :3] @ Ri), sn @ Rinv
+
+
+@pytest.mark.parametrize("with_offsets", [False, True])
+def test_lbs_backward_matches_autograd(oracle, with_offsets):
+    from mygauhuman_amd import lbs
+    V, P = 800, 2500
+    c = make_case(oracle, V, P, 11, with_offsets)
+    rng = np.random.default_rng(3)
+    gw, gt, gn = (rng.normal(0, 1, (P, 3)), rng.normal(0, 1, (P, 3, 3)), rng.normal(0, 1, (P, 3)))
+    ids = oracle.nearest_vertex(c["query"], c["big_verts"])
+    # ---- float64 autograd reference on the CPU
+    t64 = lambda a, g=False: torch.tensor(np.asarray(a, np.float64), requires_grad=g)  # noqa: E731
+    rq, rn, rA, ro = t64(c["query"], True), t64(c["normals"], True), t64(c["A_pose"], True), t64(c["off_pose"], True)
+    rl = t64(c["loff"], True) if with_offsets else None
+    w, tf, wn = _torch_deform(rq, rn, rl, t64(c["A_big"]), rA, t64(c["off_big"]), t64(c["off_shape"]), ro, t64(c["R"]),
+                              t64(c["Th"]), torch.from_numpy(ids.astype(np.int64)), t64(c["m"]["weights"]))
+    ((w * t64(gw)).sum() + (tf * t64(gt)).sum() + (wn * t64(gn)).sum()).backward()
+    # ---- HIP path
+    d = util.to_dev
+    hq, hn = d(c["query"]).requires_grad_(True), d(c["normals"]).requires_grad_(True)
+    hA, ho = d(c["A_pose"]).requires_grad_(True), d(c["off_pose"]).requires_grad_(True)
+    hl = d(c["loff"]).requires_grad_(True) if with_offsets else None
+    o = lbs.lbs_deform(hq, hn, hl, d(c["A_big"]), hA, d(c["off_big"]), d(c["off_shape"]), ho, d(c["R"]), d(c["Th"]),
+                       d(c["big_verts"]), d(c["m"]["weights"]))
+    loss = (o["world_pts"] * d(gw.astype(np.float32))).sum() + (o["transforms"] * d(gt.astype(np.float32))).sum() + \
+           (o["world_normals"] * d(gn.astype(np.float32))).sum()
+    loss.backward()
+    util.assert_close("d_query", hq.grad.cpu().numpy(), rq.grad.numpy(), tol=1e-4)
+    util.assert_close("d_normals", hn.grad.cpu().numpy(), rn.grad.numpy(), tol=1e-4)
+    util.assert_close("d_A_pose", hA.grad.cpu().numpy()[:, :3, :], rA.grad.numpy()[:, :3, :], tol=1e-4)
+    util.assert_close("d_off_pose", ho.grad.cpu().numpy(), ro.grad.numpy(), tol=1e-4)
+    if with_offsets:
+        util.assert_close("d_lbs_offsets", hl.grad.cpu().numpy(), rl.grad.numpy(), tol=1e-4)
