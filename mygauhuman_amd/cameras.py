@@ -86,3 +86,20 @@ def orbit_camera(W, H, yaw_deg, center=(0.0, 0.0, 3.5), fov_deg=50.0):
     a = math.radians(yaw_deg)
     eye = c + d * np.array([-math.sin(a), 0.0, -math.cos(a)])
     return look_at_camera(W, H, eye, c, fov_deg)
+
+
+class ViewCamera:
+    """The fields of scene.cameras.Camera (scene/cameras.py:17-74) that render() reads, as device tensors."""
+
+    def __init__(self, cam, device, smpl_param=None, big_pose_smpl_param=None, big_pose_world_vertex=None, occlusion=None):
+        import torch
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)  # noqa: E731
+        self.image_width, self.image_height = cam["W"], cam["H"]
+        self.FoVx, self.FoVy = cam["FoVx"], cam["FoVy"]
+        self.world_view_transform = t(cam["viewmatrix"])
+        self.full_proj_transform = t(cam["projmatrix"])
+        self.camera_center = t(cam["campos"])
+        self.smpl_param = smpl_param
+        self.big_pose_smpl_param = big_pose_smpl_param
+        self.big_pose_world_vertex = big_pose_world_vertex
+        self.occlusion = occlusion

@@ -1,0 +1,142 @@
+"""gaussian_renderer.render() on the MI355X hot path -- same signature and result-dict keys as the reference
+(gaussian_renderer/__init__.py:53-295; callers train.py:224,484 and render.py:200).
+
+What changes underneath:
+  * LBS deform of the canonical Gaussians      -> one HIP kernel (+ one in backward), mygauhuman_amd.lbs
+  * rasterisation                               -> mygauhuman_amd.diff_gaussian_rasterization (HIP)
+  * the reference rasterises SEVEN times per frame with identical geometry and different colours (:203-272); the calls
+    are kept (same outputs, same gradients) but go through the HIP rasterizer.
+`pc` is any object exposing the reference GaussianModel accessors (scene_model.HumanGaussianModel or the reference's own
+class); `viewpoint_camera` exposes FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
+camera_center, smpl_param, big_pose_smpl_param, big_pose_world_vertex (scene/cameras.py:17-74) and optionally
+`occlusion`.  The post-30k-iteration occlusion baking (baking.py, nvdiffrast) is outside the hot path: pass
+`viewpoint_camera.occlusion` if you have it, otherwise the opacity-derived placeholder of the reference's first 30k
+iterations is used (:141).
+"""
+import math
+
+import torch
+
+from .. import lbs as _lbs
+from ..covariance import transformVector3x3
+from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from ..sh_utils import eval_sh
+
+RESULT_KEYS = ("render", "render_depth", "render_alpha", "viewspace_points", "visibility_filter", "radii", "transforms",
+               "translation", "correct_Rs", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis")
+
+
+def _deform(pc, means3D, normal, cam, lbs_weights=None, correct_Rs=None, return_transl=False):
+    smpl = getattr(pc, "SMPL_NEUTRAL", None)
+    if isinstance(smpl, dict) and "kintree_table" in smpl:
+        return _lbs.coarse_deform_c2source(smpl, means3D[None], cam.smpl_param, cam.big_pose_smpl_param,
+                                           cam.big_pose_world_vertex[None], lbs_weights=lbs_weights, correct_Rs=correct_Rs,
+                                           return_transl=return_transl, normals=normal[None])
+    raise RuntimeError("render(): pc.SMPL_NEUTRAL (device tensors incl. kintree_table) is required for the LBS deform")
+
+
+def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None,
+           return_smpl_rot=False, transforms=None, translation=None, envmap=None):
+    """Render the scene. Background tensor (bg_color) must be on the GPU."""
+    dev = pc.get_xyz.device
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:  # noqa: BLE001
+        pass
+
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D = pc.get_xyz
+    normal = pc.get_normal
+    correct_Rs = None
+    if not pc.motion_offset_flag:
+        _, means3D, _, transforms, _, world_normal = _deform(pc, means3D, normal, viewpoint_camera)
+    elif transforms is None:
+        dst_posevec = viewpoint_camera.smpl_param["poses"][:, 3:]
+        correct_Rs = pc.pose_decoder(dst_posevec)["Rs"]
+        lbs_weights = pc.lweight_offset_decoder(means3D[None].detach()).permute(0, 2, 1)
+        _, means3D, _, transforms, translation, world_normal = _deform(pc, means3D, normal, viewpoint_camera, lbs_weights,
+                                                                       correct_Rs, return_smpl_rot)
+    else:  # cached per-pose transforms (render.py:169-195)
+        means3D = torch.matmul(transforms, means3D[..., None]).squeeze(-1) + translation
+        world_normal = torch.matmul(transforms, normal[..., None]).squeeze(-1)
+
+    means3D = means3D.squeeze()
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+
+    dir_pp = means3D - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    axis = pc.get_minimum_axis(dir_pp_normalized)
+    world_axis = torch.matmul(transforms, axis[..., None]).squeeze(-1)
+
+    albedo = pc.get_albedo
+    roughness = pc.get_roughness
+    occlusion = getattr(viewpoint_camera, "occlusion", None)
+    if iteration > 30000 and occlusion is not None:
+        occlusion = occlusion.detach()
+        if envmap is not None:
+            occ = torch.clamp(occlusion, min=0, max=1) * envmap.permute(1, 2, 0)
+            _occlusion = occ.sum(dim=(1, 2)).repeat(1, 3).clamp(min=0.0, max=1.0)
+        else:
+            _occlusion = occlusion.sum(dim=(1, 2))
+    else:
+        _occlusion = pc.get_opacity.repeat(1, 3)
+
+    viewmatrix = viewpoint_camera.world_view_transform
+    world_normal = world_normal.squeeze()
+    world_normal = world_normal / world_normal.norm(dim=1, keepdim=True)
+    world_axis = world_axis.squeeze()
+    world_axis = world_axis / world_axis.norm(dim=1, keepdim=True)
+
+    normal = transformVector3x3(world_normal, viewmatrix)
+    normal = torch.stack([normal[:, 0], -normal[:, 1], normal[:, 2]], dim=1)  # regularise to the gt normal space (:167)
+    normal = normal * 0.5 + 0.5
+    world_normal = world_normal * 0.5 + 0.5
+    axis = transformVector3x3(world_axis, viewmatrix)
+    axis = torch.stack([axis[:, 0], -axis[:, 1], axis[:, 2]], dim=1)
+    axis = axis * 0.5 + 0.5
+
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier, transforms.squeeze())
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
+            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    def raster(colors, use_shs=None):
+        return rasterizer(means3D=means3D, means2D=means2D, shs=use_shs, colors_precomp=colors, opacities=opacity,
+                          scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+    rendered_image, radii, depth, alpha = raster(colors_precomp, shs)
+    # the feature passes always use precomputed colours; with in-kernel SHs the reference would raise here (:213-272
+    # pass shs=shs AND colors_precomp), so SHs are dropped for them
+    rendered_normal = raster(normal)[0]
+    rendered_world_normal = raster(world_normal)[0]
+    rendered_albedo = raster(albedo)[0]
+    rendered_occlusion = raster(_occlusion)[0]
+    rendered_roughness = raster(roughness.mean(dim=1)[:, None].repeat(1, 3))[0]
+    rendered_axis = raster(axis)[0]
+
+    return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha, "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii, "transforms": transforms, "translation": translation,
+            "correct_Rs": correct_Rs, "normal": rendered_normal, "albedo": rendered_albedo, "occlusion": rendered_occlusion,
+            "roughness": rendered_roughness, "world_normal": rendered_world_normal, "render_axis": rendered_axis}
