@@ -159,3 +159,34 @@ def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_we
     translation = o["translation"][None] if return_transl else None
     wn = None if o["world_normals"] is None else o["world_normals"][None]
     return o["smpl_pts"][None], o["world_pts"][None], o["bweights"][None], o["transforms"][None], translation, wn
+
+
+def smplx_lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
+    """The vendored smplx `lbs()` of the reference (smplx/lbs.py:156-252, fork returns 4 values): BASELINE config 1.
+    Device-agnostic torch, batch-first: betas [B,NB], pose [B,72], v_template [1,V,3] or [V,3], shapedirs [V,3,NB],
+    posedirs [207, V*3], J_regressor [24,V], parents [24], lbs_weights [V,24] -> (verts [B,V,3], J_transformed [B,24,3],
+    A [B,24,4,4], T [B,V,4,4])."""
+    B = max(betas.shape[0], pose.shape[0])
+    vt = v_template if v_template.dim() == 3 else v_template[None]
+    v_shaped = vt + torch.einsum("bl,mkl->bmk", betas, shapedirs[..., :betas.shape[-1]])
+    J = torch.einsum("bik,ji->bjk", v_shaped, J_regressor)
+    rot_mats = batch_rodrigues(pose.reshape(-1, 3)).view(B, -1, 3, 3)
+    ident = torch.eye(3, dtype=pose.dtype, device=pose.device)
+    pose_feature = (rot_mats[:, 1:] - ident).reshape(B, -1)
+    v_posed = torch.matmul(pose_feature, posedirs).view(B, -1, 3) + v_shaped
+    # kinematic chain (batch_rigid_transform, :349-405)
+    rel = J.clone()
+    rel[:, 1:] = rel[:, 1:] - J[:, parents[1:]]
+    tm = torch.cat([torch.cat([rot_mats, rel[..., None]], dim=-1),
+                    torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=pose.dtype, device=pose.device).expand(B, J.shape[1], 1, 4)], dim=-2)
+    chain = [tm[:, 0]]
+    for i in range(1, J.shape[1]):
+        chain.append(torch.matmul(chain[int(parents[i])], tm[:, i]))
+    tr = torch.stack(chain, dim=1)
+    J_transformed = tr[:, :, :3, 3]
+    jh = torch.cat([J, torch.zeros_like(J[..., :1])], dim=-1)[..., None]
+    A = tr - torch.nn.functional.pad(torch.matmul(tr, jh), [3, 0])
+    T = torch.matmul(lbs_weights[None].expand(B, -1, -1), A.view(B, J.shape[1], 16)).view(B, -1, 4, 4)
+    vh = torch.cat([v_posed, torch.ones_like(v_posed[..., :1])], dim=2)
+    verts = torch.matmul(T, vh[..., None])[:, :, :3, 0]
+    return verts, J_transformed, A, T

@@ -1,0 +1,106 @@
+"""BASELINE.json full sizes (C2: 50k/SH0/512^2 forward, C3: 200k/SH3/1024^2 fwd+bwd), checked through
+size-independent properties: sortedness and range consistency of the binning, equality of the two binning
+back-ends and of all blend configurations, determinism of the integer state, linearity of the backward."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(P, W, H, deg):
+    from mygauhuman_amd import synthetic
+    cam, g = synthetic.uniform_scene(P, W, H, seed=0, sh_degree=deg)
+    g["cov3D"] = np.zeros((P, 6), np.float32)
+    return cam, g
+
+
+def _check_binning(f, P, W, H):
+    keys = util.hip_query(f, "KEYS_SORTED").view(np.uint64)
+    pl = util.hip_query(f, "POINT_LIST").view(np.uint32)
+    ranges = util.hip_query(f, "RANGES").view(np.uint32).astype(np.int64)
+    tt = util.hip_query(f, "TILES_TOUCHED").view(np.uint32)
+    off = util.hip_query(f, "POINT_OFFSETS").view(np.uint32)
+    R = f["R"]
+    assert R == int(tt.sum()) and int(off[-1]) == R
+    np.testing.assert_array_equal(off, np.cumsum(tt.astype(np.uint64)).astype(np.uint32))
+    assert np.all(np.diff(keys.astype(np.uint64)) >= 0) if R < 2 else bool(np.all(keys[1:] >= keys[:-1]))
+    same = keys[1:] == keys[:-1]
+    assert np.all(pl[1:][same] > pl[:-1][same])  # stability: ties keep Gaussian-index order
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    counts = np.bincount(tiles, minlength=ranges.shape[0])
+    np.testing.assert_array_equal(ranges[:, 1] - ranges[:, 0], counts)
+    nz = counts > 0
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    np.testing.assert_array_equal(ranges[nz, 0], starts[nz])
+    radii = f["radii"].cpu().numpy()
+    assert np.array_equal(np.bincount(pl, minlength=P) > 0, (radii > 0) & (tt > 0))
+    return keys, pl, ranges
+
+
+def test_c2_forward_properties():
+    from mygauhuman_amd import _lib
+    P, W, H = 50_000, 512, 512
+    cam, g = _setup(P, W, H, 0)
+    bg = np.zeros(3, np.float32)
+    res = {}
+    for mode in (_lib.BINNING_GLOBAL_RADIX, _lib.BINNING_TILE_BUCKET):
+        _lib.check(_lib.lib.gsr_set_binning_mode(mode), "mode")
+        f = util.hip_forward(cam, g, bg, "sh")
+        res[mode] = (_check_binning(f, P, W, H), f)
+    _lib.lib.gsr_set_binning_mode(_lib.DEFAULT_BINNING)
+    (ka, pa, ra), fa = res[0]
+    (kb, pb, rb), fb = res[1]
+    np.testing.assert_array_equal(ka, kb)
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ra, rb)
+    assert torch.equal(fa["color"], fb["color"]) and torch.equal(fa["alpha"], fb["alpha"])
+    a = fa["alpha"]
+    assert float(a.min()) >= 0 and float(a.max()) <= 1.0 + 1e-4
+    assert float(util.to_dev(util.hip_query(fa, "FINAL_T")).min()) >= 0
+
+
+def test_c3_forward_backward_properties():
+    from mygauhuman_amd import _lib, synthetic
+    P, W, H = 200_000, 1024, 1024
+    cam, g = _setup(P, W, H, 3)
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    gt, mask = synthetic.loss_targets(W, H)
+    outs = {}
+    for waves in (1, 2, 4):
+        _lib.set_tuning("blend_fwd_waves", waves)
+        _lib.set_tuning("blend_bwd_waves", waves)
+        f = util.hip_forward(cam, g, bg, "sh")
+        if waves == 4:
+            _check_binning(f, P, W, H)
+        color, alpha = f["color"].cpu().numpy(), f["alpha"].cpu().numpy()
+        dc = (np.sign(color - gt) / color.size).astype(np.float32)
+        da = (0.2 * (alpha - mask) / alpha.size).astype(np.float32)
+        dd = np.zeros_like(alpha)
+        grads = util.hip_backward(f, dc, dd, da)
+        outs[waves] = (f, color, alpha, grads, dc, da, dd)
+    f4, c4, a4, g4, dc, da, dd = outs[4]
+    assert f4["R"] > 1_000_000
+    for waves in (1, 2):
+        f, c, a, gr = outs[waves][:4]
+        # same per-pixel arithmetic up to FMA contraction choices of each template instantiation
+        assert float(np.abs(c - c4).max()) < 5e-5 and float(np.abs(a - a4).max()) < 5e-5
+        assert torch.equal(f["radii"], f4["radii"])
+        for k in g4:  # the backward only differs in summation order
+            util.assert_close(f"{k} waves{waves}", gr[k], g4[k], tol=1e-4, max_bad_frac=1e-5)
+    # linearity of the backward in the incoming gradients: grads(2 dL) = 2 grads(dL); grads(dc,0,0)+grads(0,0,da) = grads(dc,0,da)
+    g2 = util.hip_backward(f4, 2 * dc, dd, 2 * da)
+    gc = util.hip_backward(f4, dc, dd, 0 * da)
+    ga = util.hip_backward(f4, 0 * dc, dd, da)
+    for k in g4:
+        util.assert_close(f"{k} x2", g2[k], 2 * g4[k], tol=1e-4, max_bad_frac=1e-5)
+        util.assert_close(f"{k} additivity", gc[k] + ga[k], g4[k], tol=1e-4, max_bad_frac=1e-5)
+    # culled Gaussians get exactly zero gradient; visible ones finite
+    invisible = f4["radii"].cpu().numpy() == 0
+    for k, v in g4.items():
+        assert np.isfinite(v).all(), k
+        assert not np.any(v.reshape(P, -1)[invisible]), k
+    _lib.set_tuning("blend_fwd_waves", 4)
+    _lib.set_tuning("blend_bwd_waves", 4)

@@ -44,3 +44,22 @@ def test_minimum_axis_reproduces_reference_indexing():
     v = torch.tensor([[1.0, 2.0, 3.0]])
     m = torch.arange(16, dtype=torch.float32).view(4, 4)
     np.testing.assert_allclose(covariance.transformVector3x3(v, m).numpy(), (v @ m[:3, :3]).numpy())
+
+
+def test_smplx_lbs_and_rodrigues_match_reference_golden(golden_dir):
+    """Config 1 plumbing: the torch mirror of smplx lbs() against vectors from the imported reference."""
+    from mygauhuman_amd import lbs
+    g = np.load(os.path.join(golden_dir, "lbs_smpl.npz"))
+    T = torch.from_numpy
+    verts, J, A, Tm = lbs.smplx_lbs(T(g["betas"]), T(g["pose"]), T(g["smpl_v_template"]), T(g["smpl_shapedirs"]),
+                                    T(g["smpl_posedirs"]), T(g["smpl_J_regressor"]), T(g["smpl_parents"]), T(g["smpl_weights"]))
+    np.testing.assert_allclose(verts[0].numpy(), g["verts"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(J[0].numpy(), g["J_transformed"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(A[0].numpy(), g["A"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(Tm[0].numpy(), g["T"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(lbs.batch_rodrigues(T(g["rodrigues_in"])).numpy(), g["rodrigues_out"], rtol=1e-5, atol=1e-6)
+    # get_transform_params_torch builds the same A (same chain, gaussian_model.py:914-980)
+    smpl = dict(v_template=T(g["smpl_v_template"]), shapedirs=T(g["smpl_shapedirs"]), J_regressor=T(g["smpl_J_regressor"]),
+                kintree_table=torch.stack([T(g["smpl_parents"]), torch.arange(24)]))
+    A2, _, _, _ = lbs.get_transform_params_torch(smpl, dict(shapes=T(g["betas"]), poses=T(g["pose"]), R=None, Th=None))
+    np.testing.assert_allclose(A2[0].numpy(), g["A"], rtol=1e-4, atol=2e-6)
