@@ -201,8 +201,8 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {wl['desc']}; S-uniform seed 0, identity camera FoV 50deg"
-                                   + ("" if world == 1 else f"; {world} views/step, 1 view/GPU (3deg orbit), RCCL all-reduce of "
+            "config": {"workload": f"{a.workload}: {wl['desc']}; S-uniform seed 0, FoV 50deg, "
+                                   + ("identity camera" if world == 1 else f"{world} views/step, 1 view/GPU (cameras orbiting the scene centre in 3deg steps), RCCL all-reduce of "
                                       f"{(step.bucket.nbytes if step else 0) / 1e6:.1f} MB gradients"),
                        "P": P, "sh_degree": deg, "width": W, "height": H, "num_rendered_rank0": int(R),
                        "binning": "tile_bucket" if (step is not None or _lib.lib.gsr_get_binning_mode() == 1) else "global_radix",

@@ -31,10 +31,11 @@ constexpr int SORT_BIG = 8192;  // LDS capacity (keys) of the workgroup sort use
 constexpr int CSTRIDE = 16;
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_count_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
                                                                 uint32_t *counts, uint32_t *rank, uint32_t capacity) {
-  expand_block_instances(g, radii, P, gx, gy, true, [&](uint32_t inst, uint32_t, uint32_t tile, uint32_t) {
-    const uint32_t r = atomicAdd(&counts[(size_t)tile * CSTRIDE], 1u);
-    if (inst < capacity) rank[inst] = r;
-  });
+  expand_block_instances_2phase<4>(
+      g, radii, P, gx, gy, true, [&](uint32_t tile) { return atomicAdd(&counts[(size_t)tile * CSTRIDE], 1u); },
+      [&](uint32_t inst, uint32_t r) {
+        if (inst < capacity) rank[inst] = r;
+      });
 }
 
 // exclusive scan of counts[tiles] -> ranges[t] = (start, end); cursor[t] = start
@@ -111,42 +112,55 @@ __device__ __forceinline__ void bitonic_sort_block(Ptr keys, int npow2) {
 // ---- wave-level register bitonic sort: lists of up to 64 * NREG keys, one wave per tile, no LDS, no barriers ----
 // Element i of the list lives in register i / 64 of lane i % 64.  A compare-exchange at distance j >= 64 pairs two
 // registers of the same lane; at distance j < 64 it pairs lane l with lane l ^ j of the same register (two
-// ds_bpermute per 64-bit key).  The direction of a pair depends on bit k of the element index.
-template <int NREG>
-__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&key)[NREG], uint32_t lane) {
-  constexpr int N = NREG * WAVE;
+// ds_swizzle per 64-bit key for j < 32, two ds_bpermute for j = 32).  The direction of a pair depends on bit k of the element index.
+template <int NREG, int K, int J>
+__device__ __forceinline__ void bitonic_stage(uint64_t (&key)[NREG], uint32_t lane) {
+  if constexpr (J >= WAVE) {
+    constexpr int jr = J / WAVE;
 #pragma unroll
-  for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= WAVE) {
-        const int jr = j / WAVE;
-#pragma unroll
-        for (int r = 0; r < NREG; r++) {
-          if ((r & jr) == 0) {
-            const bool asc = (((r * WAVE) & k) == 0);  // k >= 128 here: decided by the register index alone
-            const uint64_t a = key[r], c = key[r | jr];
-            const bool sw = (a > c) == asc;
-            key[r] = sw ? c : a;
-            key[r | jr] = sw ? a : c;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < NREG; r++) {
-          const uint32_t i = (uint32_t)r * WAVE + lane;
-          const uint64_t mine = key[r];
-          const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mine, j, WAVE);
-          const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), j, WAVE);
-          const uint64_t other = ((uint64_t)hi << 32) | lo;
-          const bool lower = (lane & (uint32_t)j) == 0;
-          const bool asc = (i & (uint32_t)k) == 0;
-          const bool take_min = lower == asc;
-          key[r] = take_min ? (mine < other ? mine : other) : (mine > other ? mine : other);
-        }
+    for (int r = 0; r < NREG; r++) {
+      if ((r & jr) == 0) {
+        const bool asc = (((r * WAVE) & K) == 0);  // K >= 128 here: decided by the register index alone
+        const uint64_t a = key[r], c = key[r | jr];
+        const bool sw = (a > c) == asc;
+        key[r] = sw ? c : a;
+        key[r | jr] = sw ? a : c;
       }
     }
+  } else {
+#pragma unroll
+    for (int r = 0; r < NREG; r++) {
+      const uint32_t i = (uint32_t)r * WAVE + lane;
+      const uint64_t mine = key[r];
+      uint32_t lo, hi;
+      if constexpr (J < 32) {  // ds_swizzle bit-mode: lane ^ J inside each group of 32 (2.8x cheaper than ds_bpermute here)
+        lo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)mine, (J << 10) | 0x1F);
+        hi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)(mine >> 32), (J << 10) | 0x1F);
+      } else {
+        lo = (uint32_t)__shfl_xor((int)(uint32_t)mine, J, WAVE);
+        hi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), J, WAVE);
+      }
+      const uint64_t other = ((uint64_t)hi << 32) | lo;
+      const bool lower = (lane & (uint32_t)J) == 0;
+      const bool asc = (i & (uint32_t)K) == 0;
+      const bool take_min = lower == asc;
+      key[r] = take_min ? (mine < other ? mine : other) : (mine > other ? mine : other);
+    }
   }
+}
+template <int NREG, int K, int J>
+__device__ __forceinline__ void bitonic_merge(uint64_t (&key)[NREG], uint32_t lane) {
+  bitonic_stage<NREG, K, J>(key, lane);
+  if constexpr (J > 1) bitonic_merge<NREG, K, J / 2>(key, lane);
+}
+template <int NREG, int K>
+__device__ __forceinline__ void bitonic_levels(uint64_t (&key)[NREG], uint32_t lane) {
+  bitonic_merge<NREG, K, K / 2>(key, lane);
+  if constexpr (K < NREG * WAVE) bitonic_levels<NREG, K * 2>(key, lane);
+}
+template <int NREG>
+__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&key)[NREG], uint32_t lane) {
+  bitonic_levels<NREG, 2>(key, lane);
 }
 
 template <int NREG>

@@ -59,4 +59,64 @@ __device__ __forceinline__ void expand_block_instances(const GeomState &g, const
   }
 }
 
+
+// Variant for kernels whose per-instance work starts with a long-latency returning operation (an atomic): UNROLL
+// instances per lane are started back to back (tok = begin(...)) before any result is consumed (finish(..., tok)), so
+// UNROLL atomics per lane are in flight instead of one.
+template <int UNROLL, typename FB, typename FE>
+__device__ __forceinline__ void expand_block_instances_2phase(const GeomState &g, const int *radii, int P, int gx, int gy,
+                                                              bool write_offsets, FB begin, FE finish) {
+  __shared__ uint32_t s_incl[PRE_BLOCK];
+  __shared__ uint32_t s_rect[PRE_BLOCK];  // x0 | y0 << 10 | width << 20
+  const int first = blockIdx.x * PRE_BLOCK;
+  const int i = first + threadIdx.x;
+  const uint32_t bprefix = g.block_prefix[blockIdx.x];
+  uint32_t incl = 0xFFFFFFFFu, rect = 0;
+  if (i < P) {
+    incl = g.block_incl[i];
+    if (write_offsets) g.point_offsets[i] = bprefix + incl;
+    const int rad = radii[i];
+    if (rad > 0) {
+      const float4 r0 = reinterpret_cast<const float4 *>(g.recs + i)[0];
+      int x0, y0, x1, y1;
+      tile_rect(r0.x, r0.y, rad, gx, gy, x0, y0, x1, y1);
+      rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
+    }
+  }
+  s_incl[threadIdx.x] = incl;
+  s_rect[threadIdx.x] = rect;
+  __syncthreads();
+  const int nvalid = min(PRE_BLOCK, P - first);
+  const uint32_t total = s_incl[nvalid - 1];
+  for (uint32_t k0 = threadIdx.x; k0 < total; k0 += PRE_BLOCK * UNROLL) {
+    uint32_t tok[UNROLL], inst[UNROLL];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const uint32_t k = k0 + (uint32_t)u * PRE_BLOCK;
+      ok[u] = k < total;
+      inst[u] = bprefix + k;
+      tok[u] = 0;
+      if (ok[u]) {
+        int lo = 0, hi = nvalid - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_incl[mid] > k)
+            hi = mid;
+          else
+            lo = mid + 1;
+        }
+        const uint32_t start = lo == 0 ? 0u : s_incl[lo - 1];
+        const uint32_t local = k - start;
+        const uint32_t rc = s_rect[lo];
+        const uint32_t w = rc >> 20, x0 = rc & 1023u, y0 = (rc >> 10) & 1023u;
+        tok[u] = begin((y0 + local / w) * (uint32_t)gx + x0 + local % w);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+      if (ok[u]) finish(inst[u], tok[u]);
+  }
+}
+
 }  // namespace gsr

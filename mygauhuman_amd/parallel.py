@@ -23,9 +23,13 @@ def init_distributed(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        # rehearsal knobs (single-GPU boxes): GSR_DIST_BACKEND=gloo, GSR_SINGLE_DEVICE=1 puts every rank on cuda:0
+        backend = os.environ.get("GSR_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        if os.environ.get("GSR_SINGLE_DEVICE") == "1":
+            local = 0
         if device_type == "cuda":
             torch.cuda.set_device(local)
+        if device_type == "cuda" and backend == "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
