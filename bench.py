@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--binning", type=int, default=-1, help="0 global radix, 1 tile bucket (default: library default)")
+    ap.add_argument("--tune", action="append", default=[], help="key=value tuning knob (gsr_set_tuning), repeatable")
     a = ap.parse_args()
 
     from mygauhuman_amd import _lib, cameras, parallel, synthetic
@@ -121,6 +122,9 @@ def main():
     dev = torch.device("cuda", local)
     if a.binning >= 0:
         _lib.check(_lib.lib.gsr_set_binning_mode(a.binning), "gsr_set_binning_mode")
+    for kv in a.tune:
+        k, v = kv.split("=")
+        _lib.set_tuning(k, int(v))
 
     wl = WORKLOADS[a.workload]
     P, W, H, deg = wl["P"], wl["W"], wl["H"], wl["deg"]

@@ -24,6 +24,7 @@ Q = dict(DEPTHS=0, MEANS2D=1, CONIC_OPACITY=2, RGB=3, COV3D=4, TILES_TOUCHED=5, 
          POINT_LIST=8, KEYS_SORTED=9, RANGES=10, FINAL_T=11, N_CONTRIB=12)
 BINNING_GLOBAL_RADIX, BINNING_TILE_BUCKET = 0, 1
 DEFAULT_BINNING = BINNING_GLOBAL_RADIX
+DEFAULT_BWD_REDUCE = 0
 
 
 class GsrError(RuntimeError):

@@ -55,7 +55,17 @@ __device__ __forceinline__ float fold16(float x, float y) {
 //   dL_dmean2D.x = -o (A m0 + B m1) W/2, .y = -o (C m1 + B m0) H/2, dL_dconic = -o/2 (m2, m3, m4); see preprocess_bwd.hip.
 constexpr int NACC = 9;
 
-template <int SLOTS>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// RED selects how the four row-resident Gaussians are reduced over their 16 lanes:
+//   0: four DPP row steps per value (quad_perm x2, row_ror 4/8)                       -- VALU only
+//   1: two f32 MFMAs per value on the otherwise idle matrix pipe (exact f32, same sums):
+//        D1 = F x Sel   (A = the folded register: A[c][r] = F[16 r + c];  Sel[r][j] = [r == j mod 4])
+//           -> lane (j, g), register t holds F[16 (j mod 4) + 4 g + t]; the four registers are added (3 VALU adds)
+//        D2 += P x Col_k (Col_k[g][j] = [j == k])  chained over the nine values
+//           -> lane (column k, any row group), register t = total of row t's Gaussian for value k
+//      which is exactly the (row, column) layout the gradient-row atomic wants.
+template <int SLOTS, int RED>
 __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs a) {
   constexpr int WPT = 4 / SLOTS;
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
@@ -191,12 +201,27 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       }
       if (anyhit) {  // wave-uniform
         // four Gaussians x nine values reduced together; afterwards row 0/1/2/3 = Gaussian g+0 / g+2 / g+1 / g+3
-        float red[NACC];
+        float v;
+        if constexpr (RED == 0) {
+          float red[NACC];
 #pragma unroll
-        for (int k = 0; k < NACC; k++) red[k] = row16_sum(fold16(fold32(acc[0][k], acc[1][k]), fold32(acc[2][k], acc[3][k])));
-        float v = red[0];
+          for (int k = 0; k < NACC; k++) red[k] = row16_sum(fold16(fold32(acc[0][k], acc[1][k]), fold32(acc[2][k], acc[3][k])));
+          v = red[0];
 #pragma unroll
-        for (int k = 1; k < NACC; k++) v = (kcol == k) ? red[k] : v;
+          for (int k = 1; k < NACC; k++) v = (kcol == k) ? red[k] : v;
+        } else {
+          const float sel = (row == (kcol & 3)) ? 1.f : 0.f;  // Sel[r][j], this lane = (r = row, j = kcol)
+          f32x4 d2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < NACC; k++) {
+            const float f = fold16(fold32(acc[0][k], acc[1][k]), fold32(acc[2][k], acc[3][k]));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f, sel, z, 0, 0, 0);
+            const float p = (d1[0] + d1[1]) + (d1[2] + d1[3]);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(p, (kcol == k) ? 1.f : 0.f, d2, 0, 0, 0);
+          }
+          v = row == 0 ? d2[0] : (row == 1 ? d2[1] : (row == 2 ? d2[2] : d2[3]));
+        }
         const int u_of_row = ((row & 1) << 1) | (row >> 1);  // 0,2,1,3
         const bool live = kcol < NACC && ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
         if (live) {
@@ -210,6 +235,15 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
 }
 
 static int g_blend_bwd_nw = 4;
+static int g_blend_bwd_red = 0;
+int set_blend_backward_reduce(int mode) {
+  if (mode != 0 && mode != 1) {
+    set_error("blend_bwd_reduce must be 0 (DPP) or 1 (MFMA)");
+    return GSR_EINVAL;
+  }
+  g_blend_bwd_red = mode;
+  return GSR_OK;
+}
 int set_blend_backward_waves(int nw) {
   if (nw != 1 && nw != 2 && nw != 4) {
     set_error("blend_bwd_waves must be 1, 2 or 4");
@@ -222,10 +256,18 @@ int set_blend_backward_waves(int nw) {
 int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
+  if (g_blend_bwd_red == 1) {
+    switch (g_blend_bwd_nw) {
+      case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 1>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 1>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
+      default: hipLaunchKernelGGL((blend_backward_kernel<1, 1>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
+    }
+    return GSR_OK;
+  }
   switch (g_blend_bwd_nw) {
-    case 1: hipLaunchKernelGGL(blend_backward_kernel<4>, dim3(tiles), dim3(WAVE), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(blend_backward_kernel<2>, dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
-    default: hipLaunchKernelGGL(blend_backward_kernel<1>, dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
+    default: hipLaunchKernelGGL((blend_backward_kernel<1, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
   }
   return GSR_OK;
 }

@@ -102,6 +102,8 @@ static void prof_collect() {
 }
 
 int set_blend_forward_waves(int nw);
+int set_bucket_counter_stride(int s);
+int set_blend_backward_reduce(int mode);
 int set_blend_backward_waves(int nw);
 
 }  // namespace gsr
@@ -152,6 +154,8 @@ int gsr_set_tuning(const char *key, int value) {
   if (!key) return GSR_EINVAL;
   if (!strcmp(key, "blend_fwd_waves")) return set_blend_forward_waves(value);
   if (!strcmp(key, "blend_bwd_waves")) return set_blend_backward_waves(value);
+  if (!strcmp(key, "bucket_cstride")) return set_bucket_counter_stride(value);
+  if (!strcmp(key, "blend_bwd_reduce")) return set_blend_backward_reduce(value);
   set_error("unknown tuning key %s", key);
   return GSR_EINVAL;
 }

@@ -23,14 +23,18 @@ def _bg(seed):
     return np.random.default_rng(seed + 5).uniform(0, 1, 3).astype(np.float32)
 
 
-@pytest.fixture(scope="module", params=[1, 2, 4])
+@pytest.fixture(scope="module", params=[(1, 0), (2, 0), (4, 0), (4, 1), (2, 1)], ids=lambda p: f"waves{p[0]}red{p[1]}")
 def waves(request):
+    """(waves per tile, backward reduction: 0 = DPP rows, 1 = MFMA)"""
     from mygauhuman_amd import _lib
-    _lib.set_tuning("blend_fwd_waves", request.param)
-    _lib.set_tuning("blend_bwd_waves", request.param)
+    w, red = request.param
+    _lib.set_tuning("blend_fwd_waves", w)
+    _lib.set_tuning("blend_bwd_waves", w)
+    _lib.set_tuning("blend_bwd_reduce", red)
     yield request.param
     _lib.set_tuning("blend_fwd_waves", 4)
     _lib.set_tuning("blend_bwd_waves", 4)
+    _lib.set_tuning("blend_bwd_reduce", _lib.DEFAULT_BWD_REDUCE)
 
 
 @pytest.fixture(scope="module", params=["radix", "bucket"])
