@@ -28,7 +28,7 @@ constexpr int SORT_BIG = 8192;  // LDS capacity (keys) of the workgroup sort use
 // rank[instance] so that the scatter pass needs no second round of atomics.  Counter t lives at counts[t * CSTRIDE]:
 // device-scope atomics execute at the memory side and serialise per 64-byte line, so neighbouring tiles should not
 // share a line.
-static int g_cstride = 2;  // measured best on MI355X at C3 (1: 136, 2: 93, 4: 108, 16: 128 us of binning)
+static int g_cstride = 4;  // interleaved A/B on MI355X at C3, us of binning: 1: 112, 2: 106, 4: 100, 16: 126
 int set_bucket_counter_stride(int s) {
   if (s != 1 && s != 2 && s != 4 && s != 8 && s != 16) {
     set_error("bucket_cstride must be 1, 2, 4, 8 or 16");

@@ -136,11 +136,15 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       r2 = src[2];
       keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
     }
+    float4 r1 = make_float4(0, 0, 0, 0);
+    if (keep) {  // second, exact filter: ellipse {alpha >= 1/255} against the wave's pixel rectangle
+      r1 = src[1];
+      keep = ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rx0, rx1, ry0, ry1);
+    }
     const uint64_t kmask = __ballot(keep);
     const int cnt = __builtin_popcountll(kmask);
     if (keep) {
       const int slot = __builtin_popcountll(kmask & lt);
-      const float4 r1 = src[1];
       // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
       constexpr float L2E = 1.4426950408889634f;
       s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);

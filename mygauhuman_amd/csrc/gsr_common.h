@@ -242,6 +242,32 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Conservative "can this Gaussian reach alpha >= 1/255 anywhere in the pixel rectangle [x0,x1]x[y0,y1]?" used by the
+// blend kernels when they compact a tile's list for one wave (never changes a result: it only removes entries whose
+// every pixel test would say "skip").  alpha >= 1/255 needs q(d) = A dx^2 + 2 B dx dy + C dy^2 <= 2 ln(255 o); the
+// minimum of the convex quadratic over the rectangle is 0 if the centre is inside, else it lies on one of the four
+// edges (1-D quadratic, clamped).  Falls back to "keep" for a non positive-definite conic.
+__device__ __forceinline__ bool ellipse_hits_rect(float gx, float gy, float A, float B, float C, float opacity, float x0,
+                                                  float x1, float y0, float y1) {
+  if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return true;
+  const float thr = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * opacity) * 1.0001f + 0.05f;
+  // offsets d = g - p over the rectangle: dx in [gx - x1, gx - x0], dy in [gy - y1, gy - y0]
+  const float dxl = gx - x1, dxh = gx - x0, dyl = gy - y1, dyh = gy - y0;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;  // centre inside
+  float qmin = 3.0e38f;
+  const float rA = 1.0f / A, rC = 1.0f / C;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const float dx = e ? dxh : dxl;  // vertical edges: dx fixed, best dy = -B dx / C clamped
+    const float dy = fminf(dyh, fmaxf(dyl, -B * dx * rC));
+    qmin = fminf(qmin, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+    const float ey = e ? dyh : dyl;  // horizontal edges: dy fixed, best dx = -B dy / A clamped
+    const float ex = fminf(dxh, fmaxf(dxl, -B * ey * rA));
+    qmin = fminf(qmin, A * ex * ex + 2.0f * B * ex * ey + C * ey * ey);
+  }
+  return qmin <= thr;
+}
+
 // wave64 inclusive scan (uint32 add) with shuffles
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   const uint32_t lane = lane_id();
