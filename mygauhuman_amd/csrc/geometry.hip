@@ -124,9 +124,28 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, const float3 pos, const flo
   return make_float3(out[0], out[1], out[2]);
 }
 
+constexpr int SH_M = 16;           // coefficients per Gaussian at SH degree 3
+constexpr int SH_ROW = SH_M * 3;   // floats per Gaussian
+constexpr int SH_LDS_ROW = 52;     // padded LDS row (208 B): 16-byte aligned and conflict-free for ds_read_b128
+
+// STAGE_SH: the workgroup's 256 x 192-byte SH block is one contiguous 48 KB slab; it is fetched with fully coalesced
+// 16-byte loads into LDS and each thread then evaluates its own row out of LDS (a thread-per-row global access
+// touches 64 different cache lines per instruction and uses 4 bytes of each).
+template <bool STAGE_SH>
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const PreprocessArgs a) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
+  __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? PRE_BLOCK * SH_LDS_ROW : 4];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (STAGE_SH) {
+    const int first = blockIdx.x * PRE_BLOCK;
+    const int nrows = min(PRE_BLOCK, a.P - first);
+    const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * SH_ROW);
+    for (int q = threadIdx.x; q < nrows * (SH_ROW / 4); q += PRE_BLOCK) {
+      const int row = q / (SH_ROW / 4), k4 = q % (SH_ROW / 4);
+      *reinterpret_cast<float4 *>(&s_sh[row * SH_LDS_ROW + 4 * k4]) = slab[q];
+    }
+    __syncthreads();
+  }
   uint32_t tiles = 0;
   if (i < a.P) {
     int my_radius = 0;
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
           if (a.colors_precomp) {
             rgb = make_float3(a.colors_precomp[3 * (size_t)i], a.colors_precomp[3 * (size_t)i + 1], a.colors_precomp[3 * (size_t)i + 2]);
           } else {
-            rgb = sh_to_rgb(a.D, p, a.campos, a.shs + (size_t)i * a.M * 3, clamp_bits);
+            rgb = sh_to_rgb(a.D, p, a.campos, STAGE_SH ? &s_sh[threadIdx.x * SH_LDS_ROW] : a.shs + (size_t)i * a.M * 3, clamp_bits);
           }
           my_radius = radi;
           tiles = area;
@@ -226,7 +245,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
 
 int launch_preprocess_forward(const PreprocessArgs &a, hipStream_t stream) {
   if (a.P <= 0) return GSR_OK;
-  hipLaunchKernelGGL(preprocess_forward_kernel, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
+  const bool stage = a.shs && !a.colors_precomp && a.M == SH_M && (reinterpret_cast<size_t>(a.shs) % 16 == 0);
+  if (stage)
+    hipLaunchKernelGGL(preprocess_forward_kernel<true>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
+  else
+    hipLaunchKernelGGL(preprocess_forward_kernel<false>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
   return GSR_OK;
 }
 

@@ -31,11 +31,9 @@ __device__ __forceinline__ void sh_backward(int deg, const float3 pos, const flo
     dL_dsh[(k) * 3 + 1] = _w * dRGB[1]; \
     dL_dsh[(k) * 3 + 2] = _w * dRGB[2]; \
   }
-  OUT(0, bSH0);
+  // NB: within each degree block the coefficients are READ (into ddx/ddy/ddz) before their gradients are WRITTEN, so
+  // dL_dsh may alias sh (the kernel stages both through one LDS row).
   if (deg > 0) {
-    OUT(1, -bSH1 * y);
-    OUT(2, bSH1 * z);
-    OUT(3, -bSH1 * x);
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
       ddx[ch] = -bSH1 * S(3, ch);
@@ -44,11 +42,6 @@ __device__ __forceinline__ void sh_backward(int deg, const float3 pos, const flo
     }
     if (deg > 1) {
       const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      OUT(4, bSH2[0] * xy);
-      OUT(5, bSH2[1] * yz);
-      OUT(6, bSH2[2] * (2.f * zz - xx - yy));
-      OUT(7, bSH2[3] * xz);
-      OUT(8, bSH2[4] * (xx - yy));
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) {
         ddx[ch] += bSH2[0] * y * S(4, ch) + bSH2[2] * 2.f * -x * S(6, ch) + bSH2[3] * z * S(7, ch) + bSH2[4] * 2.f * x * S(8, ch);
@@ -56,13 +49,6 @@ __device__ __forceinline__ void sh_backward(int deg, const float3 pos, const flo
         ddz[ch] += bSH2[1] * y * S(5, ch) + bSH2[2] * 2.f * 2.f * z * S(6, ch) + bSH2[3] * x * S(7, ch);
       }
       if (deg > 2) {
-        OUT(9, bSH3[0] * y * (3.f * xx - yy));
-        OUT(10, bSH3[1] * xy * z);
-        OUT(11, bSH3[2] * y * (4.f * zz - xx - yy));
-        OUT(12, bSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-        OUT(13, bSH3[4] * x * (4.f * zz - xx - yy));
-        OUT(14, bSH3[5] * z * (xx - yy));
-        OUT(15, bSH3[6] * x * (xx - 3.f * yy));
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
           ddx[ch] += (bSH3[0] * S(9, ch) * 3.f * 2.f * xy + bSH3[1] * S(10, ch) * yz + bSH3[2] * S(11, ch) * -2.f * xy +
@@ -75,6 +61,29 @@ __device__ __forceinline__ void sh_backward(int deg, const float3 pos, const flo
                       bSH3[3] * S(12, ch) * 3.f * (2.f * zz - xx - yy) + bSH3[4] * S(13, ch) * 4.f * 2.f * xz +
                       bSH3[5] * S(14, ch) * (xx - yy));
         }
+      }
+    }
+  }
+  OUT(0, bSH0);
+  if (deg > 0) {
+    OUT(1, -bSH1 * y);
+    OUT(2, bSH1 * z);
+    OUT(3, -bSH1 * x);
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      OUT(4, bSH2[0] * xy);
+      OUT(5, bSH2[1] * yz);
+      OUT(6, bSH2[2] * (2.f * zz - xx - yy));
+      OUT(7, bSH2[3] * xz);
+      OUT(8, bSH2[4] * (xx - yy));
+      if (deg > 2) {
+        OUT(9, bSH3[0] * y * (3.f * xx - yy));
+        OUT(10, bSH3[1] * xy * z);
+        OUT(11, bSH3[2] * y * (4.f * zz - xx - yy));
+        OUT(12, bSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+        OUT(13, bSH3[4] * x * (4.f * zz - xx - yy));
+        OUT(14, bSH3[5] * z * (xx - yy));
+        OUT(15, bSH3[6] * x * (xx - 3.f * yy));
       }
     }
   }
@@ -133,9 +142,8 @@ __device__ __forceinline__ void cov3d_backward(const float3 sc, float mod, const
                4 * z * (dMt[1][1] + dMt[0][0]);
 }
 
-__global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBwdArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.P) return;
+// per-Gaussian body; sh_in / dsh_out point at this Gaussian's [M][3] blocks (global memory, or one LDS row for both)
+__device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs &a, int i, const float *sh_in, float *dsh_out) {
   if (!(a.radii[i] > 0)) {
     // culled Gaussian: the reference leaves the zero-initialised outputs untouched (CR/backward.cu:156,367);
     // writing the zeros here lets the host hand in uninitialised tensors (no separate fill kernels)
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
 #pragma unroll
     for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
     if (a.shs)
-      for (int k = 0; k < a.M * 3; k++) a.dL_dsh[(size_t)i * a.M * 3 + k] = 0.f;
+      for (int k = 0; k < a.M * 3; k++) dsh_out[k] = 0.f;
     return;
   }
   const float4 *row = reinterpret_cast<const float4 *>(a.grad_rows + (size_t)i * GROW);
@@ -275,9 +283,8 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
   dm[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
 
   if (a.shs) {
-    sh_backward(a.D, mean, a.campos, a.shs + (size_t)i * a.M * 3, a.clamped[i], make_float3(g1.z, g1.w, g2.x), dm,
-                a.dL_dsh + (size_t)i * a.M * 3);
-    for (int k = (a.D + 1) * (a.D + 1) * 3; k < a.M * 3; k++) a.dL_dsh[(size_t)i * a.M * 3 + k] = 0.f;  // inactive bands
+    sh_backward(a.D, mean, a.campos, sh_in, a.clamped[i], make_float3(g1.z, g1.w, g2.x), dm, dsh_out);
+    for (int k = (a.D + 1) * (a.D + 1) * 3; k < a.M * 3; k++) dsh_out[k] = 0.f;  // inactive bands
   }
   a.dL_dmean3D[3 * (size_t)i + 0] = dm[0];
   a.dL_dmean3D[3 * (size_t)i + 1] = dm[1];
@@ -296,9 +303,44 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
   }
 }
 
+constexpr int BSH_M = 16, BSH_ROW = BSH_M * 3, BSH_LDS_ROW = 52;  // see geometry.hip (padded, conflict-free LDS rows)
+
+// STAGE_SH: the workgroup's SH block (256 x 192 B, contiguous) comes in through LDS with coalesced 16-byte loads, each
+// thread works on its LDS row in place (coefficients in, gradients out) and the block goes out coalesced.
+template <bool STAGE_SH>
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? 256 * BSH_LDS_ROW : 4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (STAGE_SH) {
+    const int first = blockIdx.x * 256;
+    const int nrows = min(256, a.P - first);
+    const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * BSH_ROW);
+    for (int q = threadIdx.x; q < nrows * (BSH_ROW / 4); q += 256) {
+      const int row = q / (BSH_ROW / 4), k4 = q % (BSH_ROW / 4);
+      *reinterpret_cast<float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * k4]) = slab[q];
+    }
+    __syncthreads();
+    if (i < a.P) preprocess_backward_one(a, i, &s_sh[threadIdx.x * BSH_LDS_ROW], &s_sh[threadIdx.x * BSH_LDS_ROW]);
+    __syncthreads();
+    float4 *out = reinterpret_cast<float4 *>(a.dL_dsh + (size_t)first * BSH_ROW);
+    for (int q = threadIdx.x; q < nrows * (BSH_ROW / 4); q += 256) {
+      const int row = q / (BSH_ROW / 4), k4 = q % (BSH_ROW / 4);
+      out[q] = *reinterpret_cast<const float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * k4]);
+    }
+  } else {
+    if (i < a.P)
+      preprocess_backward_one(a, i, a.shs ? a.shs + (size_t)i * a.M * 3 : nullptr, a.shs ? a.dL_dsh + (size_t)i * a.M * 3 : nullptr);
+  }
+}
+
 int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream) {
   if (a.P <= 0) return GSR_OK;
-  hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+  const bool stage = a.shs && a.M == BSH_M && (reinterpret_cast<size_t>(a.shs) % 16 == 0) &&
+                     (reinterpret_cast<size_t>(a.dL_dsh) % 16 == 0);
+  if (stage)
+    hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
   return GSR_OK;
 }
 
