@@ -125,6 +125,38 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
                            float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D,
                            float *dL_dsh, float *dL_dscale, float *dL_drot, int debug, gsr_stream_t stream);
 
+/* Fused multi-feature variants (extension).  The reference's render() rasterises the same geometry
+ * seven times per frame with different colours (gaussian_renderer/__init__.py:203-272).  The _ex entry points blend
+ * n_extra extra colour channels (extra_features[P][n_extra], n_extra == 18 = six RGB triples, each triple composited
+ * over `background` like the main colour) in the SAME pass: out_extra[n_extra][H][W]; the backward takes
+ * dL_dout_extra[n_extra][H][W] and returns dL_dextra[P][n_extra], every geometric gradient being the sum over all
+ * images.  With extra_features == NULL / n_extra == 0 they are identical to the plain entry points. */
+int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
+                             gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
+                             int height, const float *means3D, const float *shs, const float *colors_precomp,
+                             const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+                             const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                             float tan_fovx, float tan_fovy, int prefiltered, float *out_color, float *out_depth,
+                             float *out_alpha, int *radii, int debug, int *host_num_rendered, const float *extra_features,
+                             int n_extra, float *out_extra, gsr_stream_t stream);
+int gsr_rasterize_forward_async_ex(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
+                                   int D, int M, const float *background, int width, int height, const float *means3D,
+                                   const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                                   float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                   const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                                   int *radii, int debug, uint32_t *dev_status, const float *extra_features, int n_extra,
+                                   float *out_extra, gsr_stream_t stream);
+int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+                              const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
+                              float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                              const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
+                              char *geom_buffer, char *binning_buffer, char *image_buffer, const float *dL_dpix,
+                              const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
+                              float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                              float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
+                              const float *dL_dout_extra, float *dL_dextra, gsr_stream_t stream);
+
 /* Fused gradient of L = mean|color - gt| + lambda_alpha * mean (alpha - mask)^2 (train.py:261-262 with the masks set to
  * the whole image): dL_dcolor[3][H][W] = sign(color - gt) / (3 H W), dL_dalpha[H][W] = 2 lambda (alpha - mask) / (H W). */
 int gsr_alpha_mask_loss_backward(int width, int height, const float *color, const float *alpha, const float *gt,

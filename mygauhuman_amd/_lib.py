@@ -14,7 +14,7 @@ SYMBOLS = [
     "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
-    "gsr_alpha_mask_loss_backward",
+    "gsr_alpha_mask_loss_backward", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
     "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward",
 ]
@@ -23,6 +23,7 @@ GSR_OK = 0
 Q = dict(DEPTHS=0, MEANS2D=1, CONIC_OPACITY=2, RGB=3, COV3D=4, TILES_TOUCHED=5, POINT_OFFSETS=6, CLAMPED=7,
          POINT_LIST=8, KEYS_SORTED=9, RANGES=10, FINAL_T=11, N_CONTRIB=12)
 BINNING_GLOBAL_RADIX, BINNING_TILE_BUCKET = 0, 1
+N_EXTRA = 18  # extra feature channels of the fused multi-feature blend (six RGB triples)
 DEFAULT_BINNING = BINNING_GLOBAL_RADIX
 DEFAULT_BWD_REDUCE = 0
 
@@ -65,6 +66,11 @@ def _load():
     lib.gsr_rasterize_forward_async.restype = C.c_int
     lib.gsr_alpha_mask_loss_backward.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, C.c_float, fp, fp, vp]
     lib.gsr_alpha_mask_loss_backward.restype = C.c_int
+    lib.gsr_rasterize_forward_ex.argtypes = lib.gsr_rasterize_forward.argtypes[:-1] + [fp, C.c_int, fp, vp]
+    lib.gsr_rasterize_forward_async_ex.argtypes = lib.gsr_rasterize_forward_async.argtypes[:-1] + [fp, C.c_int, fp, vp]
+    lib.gsr_rasterize_backward_ex.argtypes = lib.gsr_rasterize_backward.argtypes[:-1] + [fp, C.c_int, fp, fp, vp]
+    for _n in ("gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex"):
+        getattr(lib, _n).restype = C.c_int
     lib.gsr_query_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_dist2_workspace_bytes.argtypes = [C.c_int]
     lib.gsr_dist2_workspace_bytes.restype = sz

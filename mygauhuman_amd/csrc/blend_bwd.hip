@@ -65,9 +65,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //        D2 += P x Col_k (Col_k[g][j] = [j == k])  chained over the nine values
 //           -> lane (column k, any row group), register t = total of row t's Gaussian for value k
 //      which is exactly the (row, column) layout the gradient-row atomic wants.
-template <int SLOTS, int RED>
+// CE > 0 (SLOTS == 1 only): the backward of the fused multi-feature blend.  The extra channels enter e (one more dot
+// product per hit) and get their own colour-gradient sums sum_pix w * dL_dpix[c]; those are formed from the four kept
+// blending weights right before they are folded, so only 4 extra registers stay live during the group.  Gradient rows
+// have GROWX = 32 columns then: 0..8 as usual, 9 .. 9+CE-1 the extra colour gradients (two atomic instructions).
+template <int SLOTS, int RED, int CE>
 __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs a) {
+  static_assert(CE == 0 || SLOTS == 1, "feature channels are only built for one pixel per lane");
   constexpr int WPT = 4 / SLOTS;
+  constexpr int ROWF = CE > 0 ? GROWX : GROW;
+  __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
   __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
@@ -91,6 +98,7 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   float pxf[SLOTS], pyf[SLOTS], T[SLOTS], X[SLOTS], Tb[SLOTS];
   float dpix0[SLOTS], dpix1[SLOTS], dpix2[SLOTS], ddep[SLOTS], dalp[SLOTS];
   int lastc[SLOTS];
+  float dxp[CE > 0 ? CE : 1];  // dL_dpix of the extra channels (CE > 0 implies one pixel per lane)
   const int q0 = (int)part * SLOTS, q1 = q0 + SLOTS - 1;
   const float rx0 = (float)(tx * TILE + (q0 & 1) * 8), rx1 = (float)(tx * TILE + (q1 & 1) * 8 + 7);
   const float ry0 = (float)(ty * TILE + (q0 >> 1) * 8), ry1 = (float)(ty * TILE + (q1 >> 1) * 8 + 7);
@@ -111,7 +119,15 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     dpix2[s] = inside ? a.dL_dpix[2 * plane + p] : 0.f;
     ddep[s] = inside ? a.dL_ddepth[p] : 0.f;
     dalp[s] = inside ? a.dL_dalpha[p] : 0.f;
-    Tb[s] = T[s] * (bg0 * dpix0[s] + bg1 * dpix1[s] + bg2 * dpix2[s]);  // T_final * (bg . dL_dpix)
+    float bgd = bg0 * dpix0[s] + bg1 * dpix1[s] + bg2 * dpix2[s];
+    if (CE > 0) {
+#pragma unroll
+      for (int c = 0; c < CE; c++) {
+        dxp[c] = inside ? a.dL_dextra_pix[(size_t)c * plane + p] : 0.f;
+        bgd += (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2)) * dxp[c];
+      }
+    }
+    Tb[s] = T[s] * bgd;  // T_final * (bg . dL_dpix), over every colour channel
     X[s] = 0.f;
     maxlast = max(maxlast, lastc[s]);
   }
@@ -151,6 +167,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
       s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)));
       s_id[slot] = id;
+      if (CE > 0) {
+        const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
+#pragma unroll
+        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[slot * CE])[q] = xs[q];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -158,9 +179,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
 
     for (int g = 0; g < cnt; g += 4) {
       float acc[4][NACC];
+      float wk[4];  // blending weight of this lane's pixel for each of the four Gaussians (0 if not hit)
       uint32_t anyhit = 0;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
+        wk[u] = 0.f;
 #pragma unroll
         for (int k = 0; k < NACC; k++) acc[u][k] = 0.f;
         if (g + u < cnt) {  // wave-uniform
@@ -182,7 +205,12 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
                 const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
                 const float Tn = T[s] * rc;  // transmittance in front of this Gaussian
                 const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
-                const float e = g1.w * dpix0[s] + g2.x * dpix1[s] + g2.y * dpix2[s] + g1.z * ddep[s] + dalp[s];
+                float e = g1.w * dpix0[s] + g2.x * dpix1[s] + g2.y * dpix2[s] + g1.z * ddep[s] + dalp[s];
+                if (CE > 0) {
+#pragma unroll
+                  for (int c = 0; c < CE; c++) e += s_x[(g + u) * CE + c] * dxp[c];
+                  wk[u] = w;
+                }
                 const float dL_dalpha = Tn * e - (X[s] + Tb[s]) * rc;
                 X[s] += w * e;
                 T[s] = Tn;
@@ -227,10 +255,26 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
           v = row == 0 ? d2[0] : (row == 1 ? d2[1] : (row == 2 ? d2[2] : d2[3]));
         }
         const int u_of_row = ((row & 1) << 1) | (row >> 1);  // 0,2,1,3
-        const bool live = kcol < NACC && ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
-        if (live) {
-          const uint32_t gid = s_id[g + u_of_row];
-          atomicAdd(&a.grad_rows[(size_t)gid * GROW + kcol], v);
+        const bool row_live = ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
+        const uint32_t gid = row_live ? s_id[g + u_of_row] : 0u;
+        if (CE == 0) {
+          if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], v);
+        } else {
+          // extra colour gradients: columns 9..15 ride in the first atomic, 16..(9+CE-1) in a second one
+          float v1 = 0.f;
+#pragma unroll
+          for (int c = 0; c < CE; c++) {
+            const float r = row16_sum(fold16(fold32(wk[0] * dxp[c], wk[1] * dxp[c]), fold32(wk[2] * dxp[c], wk[3] * dxp[c])));
+            const int col = NACC + c;
+            if (col < 16)
+              v = (kcol == col) ? r : v;
+            else
+              v1 = (kcol == col - 16) ? r : v1;
+          }
+          if (row_live) {
+            atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], v);
+            if (kcol < NACC + CE - 16) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + 16 + kcol], v1);
+          }
         }
       }
     }
@@ -260,18 +304,26 @@ int set_blend_backward_waves(int nw) {
 int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
+  if (a.CE != 0) {
+    if (a.CE != CE_MAX || !a.extra || !a.dL_dextra_pix) {
+      set_error("fused feature blend backward: exactly %d extra channels with their arrays are required", CE_MAX);
+      return GSR_EINVAL;
+    }
+    hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    return GSR_OK;
+  }
   if (g_blend_bwd_red == 1) {
     switch (g_blend_bwd_nw) {
-      case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 1>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
-      case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 1>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
-      default: hipLaunchKernelGGL((blend_backward_kernel<1, 1>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
+      case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 1, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 1, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
+      default: hipLaunchKernelGGL((blend_backward_kernel<1, 1, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
     }
     return GSR_OK;
   }
   switch (g_blend_bwd_nw) {
-    case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
-    default: hipLaunchKernelGGL((blend_backward_kernel<1, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 0, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 0, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
+    default: hipLaunchKernelGGL((blend_backward_kernel<1, 0, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
   }
   return GSR_OK;
 }

@@ -24,9 +24,12 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
   return start + k;
 }
 
-template <int SLOTS>
+// CE > 0: fused multi-feature blend -- CE extra colour channels (a.extra[P][CE]) are composited with the same weights in
+// the same pass (the reference rasterises seven times per frame for them, gaussian_renderer/__init__.py:203-272).
+template <int SLOTS, int CE>
 __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs a) {
   constexpr int WPT = 4 / SLOTS;  // waves per tile
+  __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];  // survivors' extra channels
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
   __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), list position + 1 (bits)
@@ -39,6 +42,7 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   const int n = (int)(range.y - range.x);
 
   float pxf[SLOTS], pyf[SLOTS], T[SLOTS], C0[SLOTS], C1[SLOTS], C2[SLOTS], Dp[SLOTS], Wt[SLOTS];
+  float X[SLOTS][CE > 0 ? CE : 1];
   uint32_t last[SLOTS];
   bool inside[SLOTS], done[SLOTS];
   int pixid[SLOTS];
@@ -58,6 +62,8 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
     pixid[s] = py * a.W + px;
     T[s] = 1.0f;
     C0[s] = C1[s] = C2[s] = Dp[s] = Wt[s] = 0.f;
+#pragma unroll
+    for (int c = 0; c < (CE > 0 ? CE : 1); c++) X[s][c] = 0.f;
     last[s] = 0;
   }
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -73,8 +79,9 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
     bool keep = false;
     float4 r0 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
     const float4 *src = nullptr;
+    uint32_t id = 0;
     if (idx < n) {
-      const uint32_t id = a.point_list[range.x + idx];
+      id = a.point_list[range.x + idx];
       src = reinterpret_cast<const float4 *>(a.recs + id);
       r0 = src[0];
       r2 = src[2];
@@ -94,6 +101,11 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
       s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
       s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
       s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(idx + 1)));
+      if (CE > 0) {
+        const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
+#pragma unroll
+        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[slot * CE])[q] = xs[q];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -123,6 +135,10 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
           C2[s] += g2.y * w;
           Dp[s] += g1.z * w;
           Wt[s] += w;
+          if (CE > 0) {
+#pragma unroll
+            for (int c = 0; c < CE; c++) X[s][c] += s_x[k * CE + c] * w;
+          }
           T[s] = blend ? test_T : T[s];
           last[s] = blend ? __float_as_uint(g2.w) : last[s];
         }
@@ -144,6 +160,10 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
       a.out_color[2 * plane + p] = C2[s] + T[s] * bg2;
       a.out_alpha[p] = Wt[s];  // CR/forward.cu:380
       a.out_depth[p] = Dp[s];
+      if (CE > 0) {
+#pragma unroll
+        for (int c = 0; c < CE; c++) a.out_extra[(size_t)c * plane + p] = X[s][c] + T[s] * (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2));
+      }
     }
   }
 }
@@ -161,10 +181,18 @@ int set_blend_forward_waves(int nw) {
 int launch_blend_forward(const BlendFwdArgs &a, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
+  if (a.CE != 0) {
+    if (a.CE != CE_MAX || !a.extra || !a.out_extra) {
+      set_error("fused feature blend: exactly %d extra channels with input and output arrays are required", CE_MAX);
+      return GSR_EINVAL;
+    }
+    hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    return GSR_OK;
+  }
   switch (g_blend_fwd_nw) {
-    case 1: hipLaunchKernelGGL(blend_forward_kernel<4>, dim3(tiles), dim3(WAVE), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(blend_forward_kernel<2>, dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
-    default: hipLaunchKernelGGL(blend_forward_kernel<1>, dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((blend_forward_kernel<4, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((blend_forward_kernel<2, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
+    default: hipLaunchKernelGGL((blend_forward_kernel<1, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
   }
   return GSR_OK;
 }

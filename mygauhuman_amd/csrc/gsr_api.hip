@@ -185,6 +185,9 @@ struct FwdIn {
   float scale_modifier, tan_fovx, tan_fovy;
   float *out_color, *out_depth, *out_alpha;
   int *radii;
+  const float *extra;  // optional [P][n_extra] feature channels for the fused multi-feature blend
+  int n_extra;
+  float *out_extra;    // [n_extra][H][W]
 };
 
 int validate_forward(const FwdIn &in, const char *who) {
@@ -302,6 +305,9 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   fa.out_alpha = in.out_alpha;
   fa.final_T = img.final_T;
   fa.n_contrib = img.n_contrib;
+  fa.extra = in.extra;
+  fa.CE = in.n_extra;
+  fa.out_extra = in.out_extra;
   prof_begin(PROF_BLEND_FWD, stream);
   rc = launch_blend_forward(fa, stream);
   prof_end(PROF_BLEND_FWD, stream);
@@ -314,13 +320,14 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
 
 extern "C" {
 
-int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
-                          gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
-                          int height, const float *means3D, const float *shs, const float *colors_precomp,
-                          const float *opacities, const float *scales, float scale_modifier, const float *rotations,
-                          const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
-                          float tan_fovx, float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
-                          int *radii, int debug, int *host_num_rendered, gsr_stream_t stream_) {
+int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
+                             gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
+                             int height, const float *means3D, const float *shs, const float *colors_precomp,
+                             const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+                             const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                             float tan_fovx, float tan_fovy, int prefiltered, float *out_color, float *out_depth,
+                             float *out_alpha, int *radii, int debug, int *host_num_rendered, const float *extra_features,
+                             int n_extra, float *out_extra, gsr_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (host_num_rendered) *host_num_rendered = 0;
   if (!geometry_alloc || !binning_alloc || !image_alloc || !host_num_rendered) {
@@ -329,7 +336,7 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
   }
   const FwdIn in = {P, D, M, width, height, prefiltered, debug, background, means3D, shs, colors_precomp, opacities, scales,
                     rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, scale_modifier, tan_fovx, tan_fovy, out_color,
-                    out_depth, out_alpha, radii};
+                    out_depth, out_alpha, radii, extra_features, n_extra, out_extra};
   int rc = validate_forward(in, "gsr_rasterize_forward");
   if (rc != GSR_OK) return rc;
   if (P == 0) return GSR_OK;  // DGR/rasterize_points.cu:84
@@ -375,17 +382,31 @@ size_t gsr_binning_bytes(size_t capacity, int width, int height) {
   return binning_bytes(capacity, tiles);
 }
 
-int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
-                                int D, int M, const float *background, int width, int height, const float *means3D,
-                                const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
-                                float scale_modifier, const float *rotations, const float *cov3D_precomp,
-                                const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
-                                float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
-                                int *radii, int debug, uint32_t *dev_status, gsr_stream_t stream_) {
+int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
+                          gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
+                          int height, const float *means3D, const float *shs, const float *colors_precomp,
+                          const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+                          const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+                          float tan_fovx, float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                          int *radii, int debug, int *host_num_rendered, gsr_stream_t stream) {
+  return gsr_rasterize_forward_ex(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
+                                  background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                  rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                                  out_color, out_depth, out_alpha, radii, debug, host_num_rendered, nullptr, 0, nullptr, stream);
+}
+
+int gsr_rasterize_forward_async_ex(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
+                                   int D, int M, const float *background, int width, int height, const float *means3D,
+                                   const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                                   float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                   const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                                   int *radii, int debug, uint32_t *dev_status, const float *extra_features, int n_extra,
+                                   float *out_extra, gsr_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const FwdIn in = {P, D, M, width, height, prefiltered, debug, background, means3D, shs, colors_precomp, opacities, scales,
                     rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, scale_modifier, tan_fovx, tan_fovy, out_color,
-                    out_depth, out_alpha, radii};
+                    out_depth, out_alpha, radii, extra_features, n_extra, out_extra};
   int rc = validate_forward(in, "gsr_rasterize_forward_async");
   if (rc != GSR_OK) return rc;
   if (!geom_buffer || !binning_buffer || !image_buffer || !dev_status || P <= 0) {
@@ -403,14 +424,28 @@ int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t 
   return forward_stage_b(in, geom, bin, img, radii, -1, binning_capacity, dev_status, stream);
 }
 
-int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
-                           const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
-                           float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
-                           const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
-                           char *geom_buffer, char *binning_buffer, char *image_buffer, const float *dL_dpix,
-                           const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
-                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
-                           float *dL_dscale, float *dL_drot, int debug, gsr_stream_t stream_) {
+int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
+                                int D, int M, const float *background, int width, int height, const float *means3D,
+                                const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                                float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
+                                float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
+                                int *radii, int debug, uint32_t *dev_status, gsr_stream_t stream) {
+  return gsr_rasterize_forward_async_ex(geom_buffer, binning_buffer, binning_capacity, image_buffer, P, D, M, background, width,
+                                        height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                        cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                                        out_color, out_depth, out_alpha, radii, debug, dev_status, nullptr, 0, nullptr, stream);
+}
+
+int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+                              const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
+                              float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                              const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
+                              char *geom_buffer, char *binning_buffer, char *image_buffer, const float *dL_dpix,
+                              const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
+                              float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                              float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
+                              const float *dL_dout_extra, float *dL_dextra, gsr_stream_t stream_) {
   (void)alphas;  // unused by the reference kernel as well (CR/backward.cu:410)
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (P < 0 || R < 0 || width <= 0 || height <= 0) {
@@ -435,7 +470,12 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
   ImageState img = image_from_chunk(image_buffer, npix, tiles);
   if (!radii) radii = geom.internal_radii;
 
-  GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * GROW * sizeof(float), stream));
+  if (n_extra != 0 && (n_extra != CE_MAX || !extra_features || !dL_dout_extra || !dL_dextra)) {
+    set_error("gsr_rasterize_backward_ex: extra feature channels need n_extra == %d and all three arrays", CE_MAX);
+    return GSR_EINVAL;
+  }
+  const int grow = n_extra ? GROWX : GROW;
+  GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * grow * sizeof(float), stream));
   BlendBwdArgs ba;
   memset(&ba, 0, sizeof(ba));
   ba.ranges = img.ranges;
@@ -452,6 +492,9 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
   ba.dL_ddepth = dL_ddepths;
   ba.dL_dalpha = dL_dalphas;
   ba.grad_rows = geom.grad_rows;
+  ba.extra = extra_features;
+  ba.CE = n_extra;
+  ba.dL_dextra_pix = dL_dout_extra;
   prof_begin(PROF_BLEND_BWD, stream);
   int rc = launch_blend_backward(ba, stream);
   prof_end(PROF_BLEND_BWD, stream);
@@ -481,6 +524,9 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
   pb.focal_y = height / (2.0f * tan_fovy);
   pb.focal_x = width / (2.0f * tan_fovx);
   pb.grad_rows = geom.grad_rows;
+  pb.grow = grow;
+  pb.CE = n_extra;
+  pb.dL_dextra = dL_dextra;
   pb.recs = geom.recs;
   pb.dL_dmean2D = dL_dmean2D;
   pb.dL_dconic = dL_dconic;
@@ -497,6 +543,21 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;
+}
+
+int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+                           const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
+                           float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                           const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
+                           char *geom_buffer, char *binning_buffer, char *image_buffer, const float *dL_dpix,
+                           const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
+                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                           float *dL_dscale, float *dL_drot, int debug, gsr_stream_t stream) {
+  return gsr_rasterize_backward_ex(P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales,
+                                   scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                                   radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D,
+                                   dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug,
+                                   nullptr, 0, nullptr, nullptr, stream);
 }
 
 int gsr_query_state(int what, int P, int R, int width, int height, const char *geom_buffer, const char *binning_buffer,

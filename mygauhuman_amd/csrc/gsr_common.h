@@ -24,7 +24,10 @@ static_assert(sizeof(SplatRec) == 48, "SplatRec layout");
 
 // Packed per-Gaussian gradient row written by the blend backward (one 64-B line per Gaussian so that a
 // Gaussian's nine float atomics are one memory-side request): see blend_bwd.hip.
-constexpr int GROW = 16;  // floats per row: [0]=dmean2D.x [1]=dmean2D.y [2..4]=dconic.x,.y,.w [5]=dopacity [6..8]=dcolor
+constexpr int GROW = 16;   // floats per row (3 colour channels): [0]=dmean2D.x [1]=dmean2D.y [2..4]=dconic.x,.y,.w [5]=dopacity [6..8]=dcolor
+
+constexpr int GROWX = 32;  // floats per row when extra feature channels are blended too (9 + up to 18 colour gradients)
+constexpr int CE_MAX = 18; // extra feature channels supported by the fused multi-feature blend (6 RGB triples)
 
 struct GeomState {  // per Gaussian
   SplatRec *recs;
@@ -37,7 +40,7 @@ struct GeomState {  // per Gaussian
   uint32_t *block_sums;     // [nblk]
   uint32_t *block_prefix;   // [nblk] exclusive prefix of block_sums
   uint32_t *total;          // [1] R
-  float *grad_rows;         // [P][GROW] backward accumulation rows (zeroed by the backward)
+  float *grad_rows;         // [P][GROW or GROWX] backward accumulation rows (zeroed by the backward)
 };
 struct BinningState {  // per instance
   uint64_t *keys_a;  // "unsorted" role
@@ -82,12 +85,12 @@ inline GeomState geom_from_chunk(char *chunk, size_t P) {
   carve(chunk, g.block_sums, nb);
   carve(chunk, g.block_prefix, nb);
   carve(chunk, g.total, 4);
-  carve(chunk, g.grad_rows, P * GROW);
+  carve(chunk, g.grad_rows, P * GROWX);
   return g;
 }
 inline size_t geom_bytes(size_t P) {
   GeomState g = geom_from_chunk(nullptr, P);
-  return reinterpret_cast<size_t>(g.grad_rows + P * GROW) + 256;
+  return reinterpret_cast<size_t>(g.grad_rows + P * GROWX) + 256;
 }
 inline BinningState binning_from_chunk(char *chunk, size_t R, size_t tiles = 0) {
   BinningState b;
@@ -176,6 +179,9 @@ struct BlendFwdArgs {
   const float *bg;  // device pointer [3]
   float *out_color, *out_depth, *out_alpha, *final_T;
   uint32_t *n_contrib;
+  const float *extra;  // [P][CE] extra feature channels blended with the same weights (null: none)
+  int CE;              // 0 or CE_MAX
+  float *out_extra;    // [CE][H][W]
 };
 int launch_blend_forward(const BlendFwdArgs &a, hipStream_t stream);
 
@@ -188,7 +194,10 @@ struct BlendBwdArgs {
   const float *final_T;
   const uint32_t *n_contrib;
   const float *dL_dpix, *dL_ddepth, *dL_dalpha;
-  float *grad_rows;  // [P][GROW], zeroed
+  float *grad_rows;  // [P][GROW] (CE == 0) or [P][GROWX] (CE > 0), zeroed
+  const float *extra;          // [P][CE]
+  int CE;
+  const float *dL_dextra_pix;  // [CE][H][W]
 };
 int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream);
 
@@ -202,6 +211,9 @@ struct PreprocessBwdArgs {
   int W, H;
   float tan_fovx, tan_fovy, focal_x, focal_y;
   const float *grad_rows;
+  int grow;          // row stride of grad_rows (GROW or GROWX)
+  int CE;            // extra feature channels (their gradients sit in row columns 9 .. 9+CE-1)
+  float *dL_dextra;  // [P][CE]
   const SplatRec *recs;
   float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
 };

@@ -164,9 +164,10 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
     for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
     if (a.shs)
       for (int k = 0; k < a.M * 3; k++) dsh_out[k] = 0.f;
+    for (int c = 0; c < a.CE; c++) a.dL_dextra[(size_t)i * a.CE + c] = 0.f;
     return;
   }
-  const float4 *row = reinterpret_cast<const float4 *>(a.grad_rows + (size_t)i * GROW);
+  const float4 *row = reinterpret_cast<const float4 *>(a.grad_rows + (size_t)i * a.grow);
   const float4 m0 = row[0], m1 = row[1], m2 = row[2];
   // moments -> blend gradients (CR/backward.cu:567-584), conic / opacity from the forward's splat record
   const float4 rec0 = reinterpret_cast<const float4 *>(a.recs + i)[0];
@@ -195,6 +196,8 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
   a.dL_dcolor[3 * (size_t)i + 1] = g1.w;
   a.dL_dcolor[3 * (size_t)i + 2] = g2.x;
   const float dcx = g0.z, dcy = g0.w, dcz = g1.x;
+  for (int c = 0; c < a.CE; c++)  // fused multi-feature blend: colour gradients of the extra channels pass straight through
+    a.dL_dextra[(size_t)i * a.CE + c] = a.grad_rows[(size_t)i * a.grow + 9 + c];
 
   const float *vm = a.view, *proj = a.proj;
   const float3 mean = make_float3(a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]);

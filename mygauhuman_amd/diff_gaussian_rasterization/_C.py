@@ -40,8 +40,11 @@ class _Scratch:
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
-    """RasterizeGaussiansCUDA (DGR/rasterize_points.cu:36-120)."""
+                        prefiltered, debug, extra=None):
+    """RasterizeGaussiansCUDA (DGR/rasterize_points.cu:36-120).
+
+    `extra` (extension): [P, 18] float32 feature channels blended in the same pass (fused multi-feature render); the
+    return tuple then carries a ninth element, out_extra [18, H, W]."""
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -56,6 +59,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     radii = new((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
     rendered = C.c_int(0)
+    out_extra = None
+    if extra is not None:
+        if tuple(extra.shape) != (P, _lib.N_EXTRA):
+            raise RuntimeError(f"extra must have shape (num_points, {_lib.N_EXTRA})")
+        extra = _f32c(extra, "extra")
+        out_extra = new((_lib.N_EXTRA, H, W), dtype=torch.float32, device=dev)
+        if P == 0:
+            out_extra += background.to(dev).float().repeat(_lib.N_EXTRA // 3)[:, None, None]
     if P != 0:
         M = sh.size(1) if sh.numel() != 0 else 0
         means3D, colors, opacity = _f32c(means3D, "means3D"), _f32c(colors, "colors"), _f32c(opacity, "opacity")
@@ -63,23 +74,26 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         sh, background = _f32c(sh, "sh"), _f32c(background, "background")
         viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
         with torch.cuda.device(dev):
-            rc = lib.gsr_rasterize_forward(
+            rc = lib.gsr_rasterize_forward_ex(
                 geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), int(M), ptr(background), W, H,
                 ptr(means3D), ptr(sh), ptr(colors), ptr(opacity), ptr(scales), float(scale_modifier), ptr(rotations),
                 ptr(cov3D_precomp), ptr(viewmatrix), ptr(projmatrix), ptr(campos), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
-                radii.data_ptr(), int(bool(debug)), C.byref(rendered), _stream(dev))
+                radii.data_ptr(), int(bool(debug)), C.byref(rendered), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
+                None if out_extra is None else out_extra.data_ptr(), _stream(dev))
         for s in (geom, binning, img):
             if s.error is not None:
                 raise s.error
         check(rc, "gsr_rasterize_forward")
+    if extra is not None:
+        return rendered.value, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor, out_extra
     return rendered.value, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,
-                                 debug, out=None):
+                                 debug, out=None, extra=None, dL_dout_extra=None):
     """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207).
 
     `out` (extension, keyword only in practice): dict name -> preallocated contiguous float32 tensor for any of
@@ -111,6 +125,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = _get("sh", (P, M, 3), new)
     dL_dscales = _get("scales", (P, 3), new if has_sr else torch.zeros)
     dL_drotations = _get("rotations", (P, 4), new if has_sr else torch.zeros)
+    dL_dextra = None
+    if extra is not None:
+        extra, dL_dout_extra = _f32c(extra, "extra"), _f32c(dL_dout_extra, "dL_dout_extra")
+        dL_dextra = new((P, _lib.N_EXTRA), **opts)
     if P != 0:
         means3D, colors = _f32c(means3D, "means3D"), _f32c(colors, "colors")
         scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
@@ -120,7 +138,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dout_alpha = _f32c(dL_dout_alpha, "dL_dout_alpha")
         radii = radii.contiguous()
         with torch.cuda.device(dev):
-            rc = lib.gsr_rasterize_backward(
+            rc = lib.gsr_rasterize_backward_ex(
                 P, int(degree), int(M), int(R), ptr(background), W, H, ptr(means3D), ptr(sh), ptr(colors), ptr(alphas),
                 ptr(scales), float(scale_modifier), ptr(rotations), ptr(cov3D_precomp), ptr(viewmatrix), ptr(projmatrix),
                 ptr(campos), float(tan_fovx), float(tan_fovy), ptr(radii), geomBuffer.data_ptr(),
@@ -128,8 +146,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 ptr(dL_dout_alpha), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
-                _stream(dev))
+                ptr(extra), 0 if extra is None else _lib.N_EXTRA, ptr(dL_dout_extra),
+                None if dL_dextra is None else dL_dextra.data_ptr(), _stream(dev))
         check(rc, "gsr_rasterize_backward")
+    if extra is not None:
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dextra
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import _C
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_multi"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -88,6 +88,52 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
+class _RasterizeGaussiansMulti(torch.autograd.Function):
+    """Extension: ONE preprocess + binning + blend for the main colour and 18 extra feature
+    channels instead of seven rasterizer calls with identical geometry (gaussian_renderer/__init__.py:203-272)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        out = _C.rasterize_gaussians(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
+                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                                     rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, extra=extra)
+        num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra = out
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+                              imgBuffer, alpha, extra)
+        return color, radii, depth, alpha, out_extra
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha, grad_extra):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha,
+         extra) = ctx.saved_tensors
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_extra_in) = _C.rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
+            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, extra=extra, dL_dout_extra=grad_extra)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_extra_in, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors, opacities, scales, rotations, cov3Ds_precomp,
+                              raster_settings):
+    """Blend the main colour (SHs or colors_precomp) and up to six extra [P,3] colour sets in one pass.
+    Returns (color, radii, depth, alpha, [image_i [3,H,W] for each extra colour set])."""
+    n = len(extra_colors)
+    if not 1 <= n <= 6:
+        raise Exception("rasterize_gaussians_multi takes 1 to 6 extra colour sets")
+    P = means3D.shape[0]
+    cols = list(extra_colors) + [torch.zeros((P, 3), dtype=means3D.dtype, device=means3D.device)] * (6 - n)
+    extra = torch.cat(cols, dim=1)
+    color, radii, depth, alpha, out_extra = _RasterizeGaussiansMulti.apply(
+        means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+    return color, radii, depth, alpha, [out_extra[3 * i:3 * i + 3] for i in range(n)]
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
@@ -114,3 +160,18 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)
+
+    def forward_multi(self, means3D, means2D, opacities, extra_colors, shs=None, colors_precomp=None, scales=None, rotations=None,
+                      cov3D_precomp=None):
+        """Extension: like forward(), plus `extra_colors` (list of 1..6 [P,3] tensors) blended in the same pass.
+        Returns (color, radii, depth, alpha, [extra images])."""
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        return rasterize_gaussians_multi(means3D, means2D, empty if shs is None else shs,
+                                         empty if colors_precomp is None else colors_precomp, extra_colors, opacities,
+                                         empty if scales is None else scales, empty if rotations is None else rotations,
+                                         empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)

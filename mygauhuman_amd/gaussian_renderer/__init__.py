@@ -4,8 +4,9 @@
 What changes underneath:
   * LBS deform of the canonical Gaussians      -> one HIP kernel (+ one in backward), mygauhuman_amd.lbs
   * rasterisation                               -> mygauhuman_amd.diff_gaussian_rasterization (HIP)
-  * the reference rasterises SEVEN times per frame with identical geometry and different colours (:203-272); the calls
-    are kept (same outputs, same gradients) but go through the HIP rasterizer.
+  * the reference rasterises SEVEN times per frame with identical geometry and different colours (:203-272); here the
+    seven images come out of ONE fused pass (one preprocess + binning, a 21-channel blend, one backward) with the same
+    outputs and gradients; `pipe.separate_feature_passes = True` restores the seven separate calls.
 `pc` is any object exposing the reference GaussianModel accessors (scene_model.HumanGaussianModel or the reference's own
 class); `viewpoint_camera` exposes FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
 camera_center, smpl_param, big_pose_smpl_param, big_pose_world_vertex (scene/cameras.py:17-74) and optionally
@@ -126,15 +127,23 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
         return rasterizer(means3D=means3D, means2D=means2D, shs=use_shs, colors_precomp=colors, opacities=opacity,
                           scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
-    rendered_image, radii, depth, alpha = raster(colors_precomp, shs)
-    # the feature passes always use precomputed colours; with in-kernel SHs the reference would raise here (:213-272
-    # pass shs=shs AND colors_precomp), so SHs are dropped for them
-    rendered_normal = raster(normal)[0]
-    rendered_world_normal = raster(world_normal)[0]
-    rendered_albedo = raster(albedo)[0]
-    rendered_occlusion = raster(_occlusion)[0]
-    rendered_roughness = raster(roughness.mean(dim=1)[:, None].repeat(1, 3))[0]
-    rendered_axis = raster(axis)[0]
+    rough3 = roughness.mean(dim=1)[:, None].repeat(1, 3)
+    if getattr(pipe, "separate_feature_passes", False):
+        # the reference's structure: seven rasterizer calls with identical geometry (:203-272).  The feature passes
+        # always use precomputed colours; with in-kernel SHs the reference would raise there (shs AND colors_precomp)
+        rendered_image, radii, depth, alpha = raster(colors_precomp, shs)
+        rendered_normal = raster(normal)[0]
+        rendered_world_normal = raster(world_normal)[0]
+        rendered_albedo = raster(albedo)[0]
+        rendered_occlusion = raster(_occlusion)[0]
+        rendered_roughness = raster(rough3)[0]
+        rendered_axis = raster(axis)[0]
+    else:
+        # fused: one preprocess + binning + a 21-channel blend (and one backward) give the same seven images
+        rendered_image, radii, depth, alpha, feats = rasterizer.forward_multi(
+            means3D=means3D, means2D=means2D, opacities=opacity, extra_colors=[normal, world_normal, albedo, _occlusion, rough3, axis],
+            shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        rendered_normal, rendered_world_normal, rendered_albedo, rendered_occlusion, rendered_roughness, rendered_axis = feats
 
     return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha, "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0, "radii": radii, "transforms": transforms, "translation": translation,

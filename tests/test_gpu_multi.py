@@ -1,0 +1,91 @@
+"""Fused multi-feature rasterisation against the reference's structure: seven separate
+rasterizer calls with identical geometry.  Images must agree to rounding, gradients to 1e-4."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(cam, bg, deg):
+    from mygauhuman_amd.diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=cam["H"], image_width=cam["W"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=util.to_dev(bg),
+        scale_modifier=1.0, viewmatrix=util.to_dev(cam["viewmatrix"]), projmatrix=util.to_dev(cam["projmatrix"]), sh_degree=deg,
+        campos=util.to_dev(cam["campos"]), prefiltered=False, debug=False)
+
+
+@pytest.mark.parametrize("mode", ["sh", "precomp"])
+@pytest.mark.parametrize("n_extra", [1, 6])
+def test_forward_multi_equals_separate_passes(mode, n_extra):
+    from mygauhuman_amd.diff_gaussian_rasterization import GaussianRasterizer
+    P, W, H = 5000, 150, 100
+    cam, g = util.make_scene(P, W, H, 21, 3, 0.03, 0.02)
+    bg = np.array([0.3, 0.6, 0.1], np.float32)
+    rng = np.random.default_rng(4)
+    rast = GaussianRasterizer(_settings(cam, bg, 3))
+
+    def leaves():
+        t = {k: util.to_dev(v).requires_grad_(True) for k, v in g.items() if isinstance(v, np.ndarray)}
+        t["extras"] = [util.to_dev(rng.uniform(0, 1, (P, 3)).astype(np.float32)).requires_grad_(True) for _ in range(n_extra)]
+        t["means2D"] = torch.zeros((P, 3), device="cuda", requires_grad=True)
+        return t
+
+    rng = np.random.default_rng(4)
+    a = leaves()
+    rng = np.random.default_rng(4)
+    b = leaves()
+    if mode == "sh":
+        kw = lambda t: dict(shs=t["shs"], scales=t["scales"], rotations=t["rotations"])  # noqa: E731
+    else:
+        kw = lambda t: dict(colors_precomp=t["colors"], cov3D_precomp=t["cov3D"])  # noqa: E731
+    # fused
+    color, radii, depth, alpha, feats = rast.forward_multi(means3D=a["means3D"], means2D=a["means2D"], opacities=a["opacities"],
+                                                           extra_colors=a["extras"], **kw(a))
+    # separate (reference structure)
+    c0, r0, d0, a0 = rast(means3D=b["means3D"], means2D=b["means2D"], opacities=b["opacities"], **kw(b))
+    kwb = kw(b)
+    geo = {k: v for k, v in kwb.items() if k in ("scales", "rotations", "cov3D_precomp")}
+    sep = [rast(means3D=b["means3D"], means2D=b["means2D"], opacities=b["opacities"], colors_precomp=e, **geo)[0] for e in b["extras"]]
+    assert torch.equal(radii, r0)
+    np.testing.assert_allclose(color.detach().cpu().numpy(), c0.detach().cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(alpha.detach().cpu().numpy(), a0.detach().cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(depth.detach().cpu().numpy(), d0.detach().cpu().numpy(), atol=2e-4)
+    for f, s in zip(feats, sep):
+        np.testing.assert_allclose(f.detach().cpu().numpy(), s.detach().cpu().numpy(), atol=2e-5)
+    wr = np.random.default_rng(9)
+    ws = [util.to_dev(wr.normal(0, 1, (3, H, W)).astype(np.float32)) for _ in range(n_extra + 1)]
+    wa = util.to_dev(wr.normal(0, 1, (1, H, W)).astype(np.float32))
+    la = (color * ws[0]).sum() + (alpha * wa).sum() + sum((f * w).sum() for f, w in zip(feats, ws[1:]))
+    lb = (c0 * ws[0]).sum() + (a0 * wa).sum() + sum((s * w).sum() for s, w in zip(sep, ws[1:]))
+    la.backward()
+    lb.backward()
+    keys = ["means3D", "means2D", "opacities"] + (["shs", "scales", "rotations"] if mode == "sh" else ["colors", "cov3D"])
+    for k in keys:
+        util.assert_close(k, a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy(), tol=1e-4, max_bad_frac=1e-4)
+    for ea, eb in zip(a["extras"], b["extras"]):
+        util.assert_close("extra colour grad", ea.grad.cpu().numpy(), eb.grad.cpu().numpy(), tol=1e-4, max_bad_frac=1e-4)
+
+
+def test_render_fused_equals_seven_passes(oracle):
+    from mygauhuman_amd.gaussian_renderer import render
+    from tests.test_gpu_render import _human_scene
+    outs, grads = {}, {}
+    for sep in (False, True):
+        s = _human_scene(oracle, seed=2)
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep)
+        o = render(1, s.cam, s.model, pipe, util.to_dev(np.array([0.2, 0.3, 0.4], np.float32)))
+        loss = sum(o[k].mean() * (i + 1) for i, k in enumerate(("render", "normal", "albedo", "occlusion", "roughness", "world_normal",
+                                                                 "render_axis", "render_alpha")))
+        loss.backward()
+        outs[sep] = {k: v.detach().cpu().numpy() for k, v in o.items() if isinstance(v, torch.Tensor)}
+        grads[sep] = [p.grad.cpu().numpy() for p in s.model.parameters()] + [o["viewspace_points"].grad.cpu().numpy()]
+    for k in ("render", "render_depth", "render_alpha", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis"):
+        np.testing.assert_allclose(outs[False][k], outs[True][k], atol=3e-5, err_msg=k)
+    np.testing.assert_array_equal(outs[False]["radii"], outs[True]["radii"])
+    for ga, gb in zip(grads[False], grads[True]):
+        util.assert_close("render grads", ga, gb, tol=1e-4, max_bad_frac=2e-4)
