@@ -224,6 +224,39 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
                      float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
                      float *dL_doff_pose, gsr_stream_t stream);
 
+/* Per-frame, per-Gaussian attributes render() derives between the LBS deform and the rasterizer
+ * (gaussian_renderer/__init__.py:128-198; scene/gaussian_model.py:35-42,186-190; utils/general_utils.py:64-157;
+ * utils/sh_utils.py:57-117; transform.py:9-17) -- one kernel instead of the reference's torch op chain.
+ * Inputs, P rows each: means3D[3] (world), transforms[9] (row-major LBS rotation), world_normals[3] (LBS-rotated canonical
+ *   normal, any length), scales[3] (activated), rot_cov[4] (raw quaternion of get_covariance, normalised inside),
+ *   rot_axis[4] (quaternion of get_minimum_axis, normalised inside), albedo[3], roughness[3], occlusion[3],
+ *   shs[M][3] or null (null: no colours), campos[3], viewmatrix[16] (row-vector convention, as the rasterizer's).
+ * Outputs: cov3D[P][6] (upper triangle of T R S S R^T T^T, S = scale_modifier*scales), colors[P][3] =
+ *   max(SH_sh_degree(dir) + 0.5, 0) (needs shs), features[P][18] = normal | world_normal | albedo | occlusion |
+ *   roughness mean x3 | minimum axis, i.e. the `extra_features` array of gsr_rasterize_forward_ex.
+ * Equal scales: the minimum-axis order is the stable one (lowest index first); torch.argsort leaves it unspecified. */
+int gsr_frame_attributes_forward(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                 const float *world_normals, const float *scales, float scale_modifier,
+                                 const float *rot_cov, const float *rot_axis, const float *albedo,
+                                 const float *roughness, const float *occlusion, const float *shs,
+                                 const float *campos, const float *viewmatrix, float *cov3D, float *colors,
+                                 float *features, gsr_stream_t stream);
+
+/* Backward of gsr_frame_attributes_forward (what autograd derives for the reference's op chain).  Incoming gradients
+ * dL_dcov3D[P][6], dL_dcolors[P][3], dL_dfeatures[P][18] may each be null (= zero).  Every outgoing array is fully
+ * written (no accumulation): dL_dmeans3D[P][3] (view-direction dependence of the colours), dL_dtransforms[P][9],
+ * dL_dworld_normals[P][3], dL_dscales[P][3], dL_drot_cov[P][4], dL_drot_axis[P][4], dL_dalbedo / dL_droughness /
+ * dL_docclusion [P][3], dL_dshs[P][M][3] (required iff shs is given). */
+int gsr_frame_attributes_backward(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                  const float *world_normals, const float *scales, float scale_modifier,
+                                  const float *rot_cov, const float *rot_axis, const float *albedo,
+                                  const float *roughness, const float *occlusion, const float *shs,
+                                  const float *campos, const float *viewmatrix, const float *dL_dcov3D,
+                                  const float *dL_dcolors, const float *dL_dfeatures, float *dL_dmeans3D,
+                                  float *dL_dtransforms, float *dL_dworld_normals, float *dL_dscales,
+                                  float *dL_drot_cov, float *dL_drot_axis, float *dL_dalbedo, float *dL_droughness,
+                                  float *dL_docclusion, float *dL_dshs, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ SYMBOLS = [
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
-    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward",
+    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward",
 ]
 
 GSR_OK = 0
@@ -81,7 +81,9 @@ def _load():
     lib.gsr_sort_pairs_u32.argtypes = [sz, vp, vp, vp, vp, C.c_int, vp, sz, vp]
     lib.gsr_lbs_forward.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp]
     lib.gsr_lbs_backward.argtypes = [C.c_int, C.c_int, fp, fp, ip] + [fp] * 8 + [fp] * 3 + [fp] * 5 + [vp]
-    for name in ("gsr_set_binning_mode", "gsr_set_tuning", "gsr_mark_visible", "gsr_rasterize_forward",
+    lib.gsr_frame_attributes_forward.argtypes = [C.c_int] * 3 + [fp] * 4 + [C.c_float] + [fp] * 8 + [fp] * 3 + [vp]
+    lib.gsr_frame_attributes_backward.argtypes = [C.c_int] * 3 + [fp] * 4 + [C.c_float] + [fp] * 8 + [fp] * 3 + [fp] * 10 + [vp]
+    for name in ("gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_set_binning_mode", "gsr_set_tuning", "gsr_mark_visible", "gsr_rasterize_forward",
                  "gsr_rasterize_backward", "gsr_query_state", "gsr_dist2", "gsr_sort_pairs_u64", "gsr_sort_pairs_u32",
                  "gsr_lbs_forward", "gsr_lbs_backward"):
         getattr(lib, name).restype = C.c_int

@@ -1,0 +1,99 @@
+"""Per-frame Gaussian attributes of gaussian_renderer.render() (gaussian_renderer/__init__.py:128-198): the 3D covariance
+in the posed frame, the view-dependent colour and the six feature colour sets (normal, world normal, albedo, occlusion,
+roughness, minimum axis).
+
+    frame_attributes(...)        one HIP kernel forward + one backward (csrc/attributes.hip); tensors must live on the GPU
+    frame_attributes_torch(...)  the reference's chain of torch ops, written bmm-free -- the fp32 reference the parity
+                                 tests compare the kernel with, and what render() runs with pipe.torch_attributes=True
+Both return (cov3D [P,6], colors [P,3] or None, features [P,18]) with
+features = cat(normal, world_normal, albedo, occlusion, roughness.mean x3, axis) -- the `extra` operand of
+diff_gaussian_rasterization.rasterize_gaussians_multi.
+"""
+import torch
+
+from . import covariance
+from ._lib import check, lib, ptr
+from .sh_utils import eval_sh
+
+
+def _view_colour(v, viewmatrix):
+    t = covariance.transformVector3x3(v, viewmatrix)
+    return torch.stack([t[:, 0], -t[:, 1], t[:, 2]], dim=1) * 0.5 + 0.5  # regularise to the gt normal space (:167)
+
+
+def frame_attributes_torch(means3D, transforms, world_normals, scales, scale_modifier, rot_cov, rot_axis, albedo, roughness,
+                           occlusion, shs, sh_degree, campos, viewmatrix):
+    dir_pp = means3D - campos.reshape(1, 3)
+    dirn = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    axis, _ = covariance.flip_align_view(covariance.get_minimum_axis(scales, rot_axis), dirn)
+    axis = axis / axis.norm(dim=1, keepdim=True)
+    world_axis = covariance.bmm3(transforms, axis[..., None]).squeeze(-1)
+    world_axis = world_axis / world_axis.norm(dim=1, keepdim=True)
+    wn = world_normals / world_normals.norm(dim=1, keepdim=True)
+    cov3D = covariance.build_covariance_from_scaling_rotation(scales, scale_modifier, rot_cov, transforms)
+    colors = None
+    if shs is not None:
+        colors = torch.clamp_min(eval_sh(sh_degree, shs.transpose(1, 2), dirn) + 0.5, 0.0)
+    rough3 = roughness.mean(dim=1)[:, None].repeat(1, 3)
+    features = torch.cat([_view_colour(wn, viewmatrix), wn * 0.5 + 0.5, albedo, occlusion, rough3,
+                          _view_colour(world_axis, viewmatrix)], dim=1)
+    return cov3D, colors, features
+
+
+class _FrameAttributes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, transforms, world_normals, scales, rot_cov, rot_axis, albedo, roughness, occlusion, shs, campos,
+                viewmatrix, scale_modifier, sh_degree):
+        if not means3D.is_cuda:
+            raise RuntimeError("frame_attributes: tensors must live on a HIP device (no CPU path)")
+        dev, f32 = means3D.device, torch.float32
+        P = means3D.shape[0]
+        c = lambda t: None if t is None else t.detach().contiguous().float()  # noqa: E731
+        ins = [c(means3D), c(transforms).reshape(P, 9), c(world_normals), c(scales), c(rot_cov), c(rot_axis), c(albedo),
+               c(roughness), c(occlusion), c(shs), c(campos).reshape(3), c(viewmatrix).reshape(16)]
+        M = 0 if shs is None else int(shs.shape[1])
+        cov3D = torch.empty((P, 6), dtype=f32, device=dev)
+        colors = torch.empty((P, 3), dtype=f32, device=dev) if shs is not None else None
+        features = torch.empty((P, 18), dtype=f32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gsr_frame_attributes_forward(
+                P, int(sh_degree), M, ptr(ins[0]), ptr(ins[1]), ptr(ins[2]), ptr(ins[3]), float(scale_modifier), ptr(ins[4]),
+                ptr(ins[5]), ptr(ins[6]), ptr(ins[7]), ptr(ins[8]), ptr(ins[9]), ptr(ins[10]), ptr(ins[11]), ptr(cov3D),
+                ptr(colors), ptr(features), torch.cuda.current_stream(dev).cuda_stream), "gsr_frame_attributes_forward")
+        ctx.has_shs = shs is not None
+        ctx.save_for_backward(*[t for t in ins if t is not None])
+        ctx.meta = (float(scale_modifier), int(sh_degree), M, transforms.shape)
+        return cov3D, (colors if colors is not None else torch.empty(0, device=dev)), features
+
+    @staticmethod
+    def backward(ctx, g_cov, g_colors, g_features):
+        saved = list(ctx.saved_tensors)
+        if not ctx.has_shs:
+            saved.insert(9, None)
+        means3D, transforms, wn, scales, rot_cov, rot_axis, albedo, roughness, occlusion, shs, campos, view = saved
+        mod, D, M, t_shape = ctx.meta
+        dev, f32 = means3D.device, torch.float32
+        P = means3D.shape[0]
+        c = lambda t: None if t is None else t.contiguous().float()  # noqa: E731
+        g_colors = c(g_colors) if (ctx.has_shs and g_colors is not None and g_colors.numel()) else None
+        new = lambda *s: torch.empty(s, dtype=f32, device=dev)  # noqa: E731
+        d_means, d_T, d_wn, d_scales, d_rc, d_ra = new(P, 3), new(P, 9), new(P, 3), new(P, 3), new(P, 4), new(P, 4)
+        d_alb, d_rough, d_occ = new(P, 3), new(P, 3), new(P, 3)
+        d_shs = new(P, M, 3) if ctx.has_shs else None
+        with torch.cuda.device(dev):
+            check(lib.gsr_frame_attributes_backward(
+                P, D, M, ptr(means3D), ptr(transforms), ptr(wn), ptr(scales), mod, ptr(rot_cov), ptr(rot_axis), ptr(albedo),
+                ptr(roughness), ptr(occlusion), ptr(shs), ptr(campos), ptr(view), ptr(c(g_cov)), ptr(g_colors),
+                ptr(c(g_features)), ptr(d_means), ptr(d_T), ptr(d_wn), ptr(d_scales), ptr(d_rc), ptr(d_ra), ptr(d_alb),
+                ptr(d_rough), ptr(d_occ), ptr(d_shs), torch.cuda.current_stream(dev).cuda_stream),
+                "gsr_frame_attributes_backward")
+        return (d_means, d_T.view(t_shape), d_wn, d_scales, d_rc, d_ra, d_alb, d_rough, d_occ, d_shs, None, None, None, None)
+
+
+def frame_attributes(means3D, transforms, world_normals, scales, scale_modifier, rot_cov, rot_axis, albedo, roughness, occlusion,
+                     shs, sh_degree, campos, viewmatrix):
+    """HIP path.  means3D [P,3], transforms [P,3,3], world_normals [P,3] (un-normalised), scales [P,3] (activated),
+    rot_cov / rot_axis [P,4], albedo / roughness / occlusion [P,3], shs [P,M,3] or None."""
+    cov3D, colors, features = _FrameAttributes.apply(means3D, transforms, world_normals, scales, rot_cov, rot_axis, albedo,
+                                                     roughness, occlusion, shs, campos, viewmatrix, scale_modifier, sh_degree)
+    return cov3D, (colors if shs is not None else None), features

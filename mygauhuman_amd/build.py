@@ -20,6 +20,7 @@ SOURCES = [
     ("blend_bwd.hip", []),
     ("preprocess_bwd.hip", []),
     ("lbs.hip", []),
+    ("attributes.hip", []),
     ("loss.hip", []),
     ("gsr_api.hip", []),
 ]

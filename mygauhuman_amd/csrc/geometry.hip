@@ -9,15 +9,9 @@
 // cub::DeviceScan::InclusiveSum (:279), duplicateWithKeys (:70-111), identifyTileRanges (:116-138).
 #include "expand.h"
 #include "gsr_common.h"
+#include "sh_math.h"
 
 namespace gsr {
-
-__constant__ float kSH0 = 0.28209479177387814f;  // CR/auxiliary.h:22-39
-__constant__ float kSH1 = 0.4886025119029199f;
-__constant__ float kSH2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
-                              0.5462742152960396f};
-__constant__ float kSH3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
-                              -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
 
 __device__ __forceinline__ float3 xform4x3(const float3 p, const float *m) {
   return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
@@ -88,40 +82,6 @@ __device__ __forceinline__ float3 cov2d(const float3 mean, float fx, float fy, f
   const float c01 = A[0][1] * T0[0] + A[1][1] * T0[1] + A[2][1] * T0[2];
   const float c11 = A[0][1] * T1[0] + A[1][1] * T1[1] + A[2][1] * T1[2];
   return make_float3(c00 + 0.3f, c01, c11 + 0.3f);
-}
-
-// SH -> RGB (CR/forward.cu:20-71); sh points at this Gaussian's [M][3] block
-__device__ __forceinline__ float3 sh_to_rgb(int deg, const float3 pos, const float *campos, const float *sh,
-                                            uint32_t &clamp_bits) {
-  const float dx0 = pos.x - campos[0], dy0 = pos.y - campos[1], dz0 = pos.z - campos[2];
-  const float len = sqrtf(dx0 * dx0 + dy0 * dy0 + dz0 * dz0);
-  const float x = dx0 / len, y = dy0 / len, z = dz0 / len;
-  float out[3];
-  clamp_bits = 0;
-#pragma unroll
-  for (int ch = 0; ch < 3; ch++) {
-#define S(k) sh[(k) * 3 + ch]
-    float res = kSH0 * S(0);
-    if (deg > 0) {
-      res = res - kSH1 * y * S(1) + kSH1 * z * S(2) - kSH1 * x * S(3);
-      if (deg > 1) {
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        res = res + kSH2[0] * xy * S(4) + kSH2[1] * yz * S(5) + kSH2[2] * (2.0f * zz - xx - yy) * S(6) +
-              kSH2[3] * xz * S(7) + kSH2[4] * (xx - yy) * S(8);
-        if (deg > 2) {
-          res = res + kSH3[0] * y * (3.0f * xx - yy) * S(9) + kSH3[1] * xy * z * S(10) +
-                kSH3[2] * y * (4.0f * zz - xx - yy) * S(11) + kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12) +
-                kSH3[4] * x * (4.0f * zz - xx - yy) * S(13) + kSH3[5] * z * (xx - yy) * S(14) +
-                kSH3[6] * x * (xx - 3.0f * yy) * S(15);
-        }
-      }
-    }
-#undef S
-    res += 0.5f;
-    if (res < 0) clamp_bits |= 1u << ch;
-    out[ch] = fmaxf(res, 0.0f);
-  }
-  return make_float3(out[0], out[1], out[2]);
 }
 
 constexpr int SH_M = 16;           // coefficients per Gaussian at SH degree 3

@@ -4,101 +4,9 @@
 // dL_dcolor tensors (DGR/rasterize_points.cu:159-167,206).  GLM products are written out in GLM's column-major
 // evaluation order, m[c][r] = column c, row r.
 #include "gsr_common.h"
+#include "sh_math.h"
 
 namespace gsr {
-
-__constant__ float bSH0 = 0.28209479177387814f;  // CR/auxiliary.h:22-39
-__constant__ float bSH1 = 0.4886025119029199f;
-__constant__ float bSH2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
-                              0.5462742152960396f};
-__constant__ float bSH3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
-                              -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
-
-// CR/backward.cu:20-139
-__device__ __forceinline__ void sh_backward(int deg, const float3 pos, const float *campos, const float *sh,
-                                            uint32_t clamp_bits, const float3 dL_dcolor, float *dL_dmean, float *dL_dsh) {
-  const float d0x = pos.x - campos[0], d0y = pos.y - campos[1], d0z = pos.z - campos[2];
-  const float len = sqrtf(d0x * d0x + d0y * d0y + d0z * d0z);
-  const float x = d0x / len, y = d0y / len, z = d0z / len;
-  const float dRGB[3] = {(clamp_bits & 1u) ? 0.f : dL_dcolor.x, (clamp_bits & 2u) ? 0.f : dL_dcolor.y,
-                         (clamp_bits & 4u) ? 0.f : dL_dcolor.z};
-  float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
-#define S(k, ch) sh[(k) * 3 + (ch)]
-#define OUT(k, w)                     \
-  {                                   \
-    const float _w = (w);             \
-    dL_dsh[(k) * 3 + 0] = _w * dRGB[0]; \
-    dL_dsh[(k) * 3 + 1] = _w * dRGB[1]; \
-    dL_dsh[(k) * 3 + 2] = _w * dRGB[2]; \
-  }
-  // NB: within each degree block the coefficients are READ (into ddx/ddy/ddz) before their gradients are WRITTEN, so
-  // dL_dsh may alias sh (the kernel stages both through one LDS row).
-  if (deg > 0) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-      ddx[ch] = -bSH1 * S(3, ch);
-      ddy[ch] = -bSH1 * S(1, ch);
-      ddz[ch] = bSH1 * S(2, ch);
-    }
-    if (deg > 1) {
-      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-      for (int ch = 0; ch < 3; ch++) {
-        ddx[ch] += bSH2[0] * y * S(4, ch) + bSH2[2] * 2.f * -x * S(6, ch) + bSH2[3] * z * S(7, ch) + bSH2[4] * 2.f * x * S(8, ch);
-        ddy[ch] += bSH2[0] * x * S(4, ch) + bSH2[1] * z * S(5, ch) + bSH2[2] * 2.f * -y * S(6, ch) + bSH2[4] * 2.f * -y * S(8, ch);
-        ddz[ch] += bSH2[1] * y * S(5, ch) + bSH2[2] * 2.f * 2.f * z * S(6, ch) + bSH2[3] * x * S(7, ch);
-      }
-      if (deg > 2) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-          ddx[ch] += (bSH3[0] * S(9, ch) * 3.f * 2.f * xy + bSH3[1] * S(10, ch) * yz + bSH3[2] * S(11, ch) * -2.f * xy +
-                      bSH3[3] * S(12, ch) * -3.f * 2.f * xz + bSH3[4] * S(13, ch) * (-3.f * xx + 4.f * zz - yy) +
-                      bSH3[5] * S(14, ch) * 2.f * xz + bSH3[6] * S(15, ch) * 3.f * (xx - yy));
-          ddy[ch] += (bSH3[0] * S(9, ch) * 3.f * (xx - yy) + bSH3[1] * S(10, ch) * xz +
-                      bSH3[2] * S(11, ch) * (-3.f * yy + 4.f * zz - xx) + bSH3[3] * S(12, ch) * -3.f * 2.f * yz +
-                      bSH3[4] * S(13, ch) * -2.f * xy + bSH3[5] * S(14, ch) * -2.f * yz + bSH3[6] * S(15, ch) * -3.f * 2.f * xy);
-          ddz[ch] += (bSH3[1] * S(10, ch) * xy + bSH3[2] * S(11, ch) * 4.f * 2.f * yz +
-                      bSH3[3] * S(12, ch) * 3.f * (2.f * zz - xx - yy) + bSH3[4] * S(13, ch) * 4.f * 2.f * xz +
-                      bSH3[5] * S(14, ch) * (xx - yy));
-        }
-      }
-    }
-  }
-  OUT(0, bSH0);
-  if (deg > 0) {
-    OUT(1, -bSH1 * y);
-    OUT(2, bSH1 * z);
-    OUT(3, -bSH1 * x);
-    if (deg > 1) {
-      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      OUT(4, bSH2[0] * xy);
-      OUT(5, bSH2[1] * yz);
-      OUT(6, bSH2[2] * (2.f * zz - xx - yy));
-      OUT(7, bSH2[3] * xz);
-      OUT(8, bSH2[4] * (xx - yy));
-      if (deg > 2) {
-        OUT(9, bSH3[0] * y * (3.f * xx - yy));
-        OUT(10, bSH3[1] * xy * z);
-        OUT(11, bSH3[2] * y * (4.f * zz - xx - yy));
-        OUT(12, bSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-        OUT(13, bSH3[4] * x * (4.f * zz - xx - yy));
-        OUT(14, bSH3[5] * z * (xx - yy));
-        OUT(15, bSH3[6] * x * (xx - 3.f * yy));
-      }
-    }
-  }
-#undef S
-#undef OUT
-  const float dd0 = ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2];
-  const float dd1 = ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2];
-  const float dd2 = ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2];
-  // dnormvdv, CR/auxiliary.h:107-117
-  const float sum2 = d0x * d0x + d0y * d0y + d0z * d0z;
-  const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-  dL_dmean[0] += ((+sum2 - d0x * d0x) * dd0 - d0y * d0x * dd1 - d0z * d0x * dd2) * inv32;
-  dL_dmean[1] += (-d0x * d0y * dd0 + (sum2 - d0y * d0y) * dd1 - d0z * d0y * dd2) * inv32;
-  dL_dmean[2] += (-d0x * d0z * dd0 - d0y * d0z * dd1 + (sum2 - d0z * d0z) * dd2) * inv32;
-}
 
 // CR/backward.cu:278-341 (quaternion used as given, no normalisation Jacobian)
 __device__ __forceinline__ void cov3d_backward(const float3 sc, float mod, const float4 q, const float *d, float *dL_dscale,

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from .._lib import N_EXTRA
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_multi"]
 
@@ -121,14 +122,20 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
 
 def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors, opacities, scales, rotations, cov3Ds_precomp,
                               raster_settings):
-    """Blend the main colour (SHs or colors_precomp) and up to six extra [P,3] colour sets in one pass.
+    """Blend the main colour (SHs or colors_precomp) and up to six extra [P,3] colour sets (a list, or one packed [P,18]
+    tensor) in one pass.
     Returns (color, radii, depth, alpha, [image_i [3,H,W] for each extra colour set])."""
-    n = len(extra_colors)
-    if not 1 <= n <= 6:
-        raise Exception("rasterize_gaussians_multi takes 1 to 6 extra colour sets")
     P = means3D.shape[0]
-    cols = list(extra_colors) + [torch.zeros((P, 3), dtype=means3D.dtype, device=means3D.device)] * (6 - n)
-    extra = torch.cat(cols, dim=1)
+    if isinstance(extra_colors, torch.Tensor):  # already packed: [P, 18] = six RGB triples side by side
+        if extra_colors.dim() != 2 or extra_colors.shape[1] != N_EXTRA:
+            raise Exception("rasterize_gaussians_multi: a packed extra-colour tensor must be [P, 18]")
+        n, extra = 6, extra_colors
+    else:
+        n = len(extra_colors)
+        if not 1 <= n <= 6:
+            raise Exception("rasterize_gaussians_multi takes 1 to 6 extra colour sets")
+        cols = list(extra_colors) + [torch.zeros((P, 3), dtype=means3D.dtype, device=means3D.device)] * (6 - n)
+        extra = torch.cat(cols, dim=1)
     color, radii, depth, alpha, out_extra = _RasterizeGaussiansMulti.apply(
         means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
     return color, radii, depth, alpha, [out_extra[3 * i:3 * i + 3] for i in range(n)]

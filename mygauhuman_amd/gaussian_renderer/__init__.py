@@ -3,6 +3,7 @@
 
 What changes underneath:
   * LBS deform of the canonical Gaussians      -> one HIP kernel (+ one in backward), mygauhuman_amd.lbs
+  * covariance / SH colour / feature colours   -> one HIP kernel (+ one in backward), mygauhuman_amd.attributes
   * rasterisation                               -> mygauhuman_amd.diff_gaussian_rasterization (HIP)
   * the reference rasterises SEVEN times per frame with identical geometry and different colours (:203-272); here the
     seven images come out of ONE fused pass (one preprocess + binning, a 21-channel blend, one backward) with the same
@@ -19,9 +20,9 @@ import math
 import torch
 
 from .. import lbs as _lbs
-from ..covariance import transformVector3x3
+from ..attributes import frame_attributes, frame_attributes_torch
+from ..covariance import bmm3
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-from ..sh_utils import eval_sh
 
 RESULT_KEYS = ("render", "render_depth", "render_alpha", "viewspace_points", "visibility_filter", "radii", "transforms",
                "translation", "correct_Rs", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis")
@@ -67,18 +68,12 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
         _, means3D, _, transforms, translation, world_normal = _deform(pc, means3D, normal, viewpoint_camera, lbs_weights,
                                                                        correct_Rs, return_smpl_rot)
     else:  # cached per-pose transforms (render.py:169-195)
-        means3D = torch.matmul(transforms, means3D[..., None]).squeeze(-1) + translation
-        world_normal = torch.matmul(transforms, normal[..., None]).squeeze(-1)
+        means3D = bmm3(transforms, means3D[..., None]).squeeze(-1) + translation
+        world_normal = bmm3(transforms, normal[..., None]).squeeze(-1)
 
-    means3D = means3D.squeeze()
+    means3D = means3D.reshape(-1, 3)
     means2D = screenspace_points
     opacity = pc.get_opacity
-
-    dir_pp = means3D - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
-    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-    axis = pc.get_minimum_axis(dir_pp_normalized)
-    world_axis = torch.matmul(transforms, axis[..., None]).squeeze(-1)
-
     albedo = pc.get_albedo
     roughness = pc.get_roughness
     occlusion = getattr(viewpoint_camera, "occlusion", None)
@@ -90,59 +85,41 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
         else:
             _occlusion = occlusion.sum(dim=(1, 2))
     else:
-        _occlusion = pc.get_opacity.repeat(1, 3)
+        _occlusion = opacity.repeat(1, 3)
 
-    viewmatrix = viewpoint_camera.world_view_transform
-    world_normal = world_normal.squeeze()
-    world_normal = world_normal / world_normal.norm(dim=1, keepdim=True)
-    world_axis = world_axis.squeeze()
-    world_axis = world_axis / world_axis.norm(dim=1, keepdim=True)
+    # covariance in the posed frame, view-dependent colour and the six feature colour sets (:120-198): one HIP kernel
+    # (mygauhuman_amd.attributes); pipe.torch_attributes = True runs the reference's chain of torch ops instead
+    sh_python = override_color is None and pipe.convert_SHs_python
+    attributes = frame_attributes_torch if getattr(pipe, "torch_attributes", False) else frame_attributes
+    cov3D_precomp, colors_precomp, features = attributes(
+        means3D, transforms.reshape(-1, 3, 3), world_normal.reshape(-1, 3), pc.get_scaling, scaling_modifier, pc._rotation,
+        pc.get_rotation, albedo, roughness, _occlusion, pc.get_features if sh_python else None, pc.active_sh_degree,
+        viewpoint_camera.camera_center, viewpoint_camera.world_view_transform)
 
-    normal = transformVector3x3(world_normal, viewmatrix)
-    normal = torch.stack([normal[:, 0], -normal[:, 1], normal[:, 2]], dim=1)  # regularise to the gt normal space (:167)
-    normal = normal * 0.5 + 0.5
-    world_normal = world_normal * 0.5 + 0.5
-    axis = transformVector3x3(world_axis, viewmatrix)
-    axis = torch.stack([axis[:, 0], -axis[:, 1], axis[:, 2]], dim=1)
-    axis = axis * 0.5 + 0.5
-
-    scales = rotations = cov3D_precomp = None
-    if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier, transforms.squeeze())
-    else:
+    scales = rotations = shs = None
+    if not pipe.compute_cov3D_python:
+        cov3D_precomp = None
         scales, rotations = pc.get_scaling, pc.get_rotation
-
-    shs = colors_precomp = None
-    if override_color is None:
-        if pipe.convert_SHs_python:
-            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
-            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
-        else:
-            shs = pc.get_features
-    else:
+    if override_color is not None:
         colors_precomp = override_color
+    elif not sh_python:
+        shs = pc.get_features
 
     def raster(colors, use_shs=None):
         return rasterizer(means3D=means3D, means2D=means2D, shs=use_shs, colors_precomp=colors, opacities=opacity,
                           scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
-    rough3 = roughness.mean(dim=1)[:, None].repeat(1, 3)
     if getattr(pipe, "separate_feature_passes", False):
         # the reference's structure: seven rasterizer calls with identical geometry (:203-272).  The feature passes
         # always use precomputed colours; with in-kernel SHs the reference would raise there (shs AND colors_precomp)
         rendered_image, radii, depth, alpha = raster(colors_precomp, shs)
-        rendered_normal = raster(normal)[0]
-        rendered_world_normal = raster(world_normal)[0]
-        rendered_albedo = raster(albedo)[0]
-        rendered_occlusion = raster(_occlusion)[0]
-        rendered_roughness = raster(rough3)[0]
-        rendered_axis = raster(axis)[0]
+        (rendered_normal, rendered_world_normal, rendered_albedo, rendered_occlusion, rendered_roughness,
+         rendered_axis) = [raster(features[:, 3 * k:3 * k + 3])[0] for k in range(6)]
     else:
         # fused: one preprocess + binning + a 21-channel blend (and one backward) give the same seven images
         rendered_image, radii, depth, alpha, feats = rasterizer.forward_multi(
-            means3D=means3D, means2D=means2D, opacities=opacity, extra_colors=[normal, world_normal, albedo, _occlusion, rough3, axis],
-            shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+            means3D=means3D, means2D=means2D, opacities=opacity, extra_colors=features, shs=shs, colors_precomp=colors_precomp,
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
         rendered_normal, rendered_world_normal, rendered_albedo, rendered_occlusion, rendered_roughness, rendered_axis = feats
 
     return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha, "viewspace_points": screenspace_points,

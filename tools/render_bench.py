@@ -56,6 +56,13 @@ def main(P=200_000, V=6890, W=1024, H=1024):
             step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n * 1e3
+        if os.environ.get("PROFILE"):
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+            print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=35, max_name_column_width=60), flush=True)
         print(f"render() fwd+bwd, P={P}, {W}x{H}, visible={int((o['radii'] > 0).sum())}: "
               f"{'seven passes' if sep else 'fused'}: {dt:.2f} ms/frame", flush=True)
 
