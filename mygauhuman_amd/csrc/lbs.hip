@@ -25,11 +25,188 @@ constexpr int NJ = 24;
 constexpr int LBS_BLOCK = 256;
 constexpr int VTILE = 1024;
 
+// squared distance with one IEEE rounding per operation, (dx*dx + dy*dy) + dz*dz -- the oracle's expression; both
+// search variants use it, so the grid search returns bit-identical indices to the brute-force scan
+__device__ __forceinline__ float sqdist_exact(float vx, float vy, float vz, const float *q) {
+  const float dx = vx - q[0], dy = vy - q[1], dz = vz - q[2];
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---- uniform grid over the V reference vertices (rebuilt per call by one workgroup; V is a few thousand) ----------------
+// workspace: GridHeader | cell_start[ncell + 1] | float4 sorted[V] (x, y, z, original index bits), cells x-fastest.
+constexpr int GRID_RES = 48;                                   // cells along the longest bounding-box axis
+constexpr int GRID_MAXCELLS = (GRID_RES + 1) * (GRID_RES + 1) * (GRID_RES + 1);
+constexpr int GRID_BLOCK = 1024;
+struct GridHeader {
+  float bbmin[3], h, inv_h;
+  int dims[3];
+};
+constexpr size_t GRID_HDR_BYTES = 64;
+__host__ __device__ inline size_t grid_cells_offset() { return GRID_HDR_BYTES; }
+__host__ __device__ inline size_t grid_sorted_offset() {
+  return (GRID_HDR_BYTES + (size_t)(GRID_MAXCELLS + 1) * 4 + 15) / 16 * 16;
+}
+inline size_t grid_workspace_bytes(int V) { return grid_sorted_offset() + (size_t)V * 16; }
+
+__device__ __forceinline__ int grid_cell_coord(float x, float lo, float inv_h, int dim) {
+  const int c = (int)floorf((x - lo) * inv_h);
+  return min(max(c, 0), dim - 1);
+}
+
+__global__ __launch_bounds__(GRID_BLOCK) void lbs_grid_build_kernel(int V, const float *verts, char *ws) {
+  __shared__ float s_red[6][GRID_BLOCK / WAVE];
+  __shared__ GridHeader s_h;
+  __shared__ uint32_t s_scan[GRID_BLOCK];
+  GridHeader *hdr = reinterpret_cast<GridHeader *>(ws);
+  uint32_t *cells = reinterpret_cast<uint32_t *>(ws + grid_cells_offset());
+  float4 *sorted = reinterpret_cast<float4 *>(ws + grid_sorted_offset());
+  const int t = threadIdx.x;
+  // bounding box
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int v = t; v < V; v += GRID_BLOCK)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float x = verts[3 * (size_t)v + k];
+      lo[k] = fminf(lo[k], x);
+      hi[k] = fmaxf(hi[k], x);
+    }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+    }
+    if ((t & 63) == 0) {
+      s_red[k][t >> 6] = lo[k];
+      s_red[3 + k][t >> 6] = hi[k];
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    float ext = 0.f;
+    for (int k = 0; k < 3; k++) {
+      float l = FLT_MAX, h = -FLT_MAX;
+      for (int w = 0; w < GRID_BLOCK / WAVE; w++) {
+        l = fminf(l, s_red[k][w]);
+        h = fmaxf(h, s_red[3 + k][w]);
+      }
+      lo[k] = l;
+      hi[k] = h;
+      ext = fmaxf(ext, h - l);
+    }
+    const float h = fmaxf(ext / (float)GRID_RES, 1e-12f);
+    s_h.h = h;
+    s_h.inv_h = 1.0f / h;
+    for (int k = 0; k < 3; k++) {
+      s_h.bbmin[k] = lo[k];
+      s_h.dims[k] = min(GRID_RES + 1, (int)floorf((hi[k] - lo[k]) / h) + 1);
+    }
+    *hdr = s_h;
+  }
+  __syncthreads();
+  const GridHeader g = s_h;
+  const int ncell = g.dims[0] * g.dims[1] * g.dims[2];
+  for (int c = t; c <= ncell; c += GRID_BLOCK) cells[c] = 0u;
+  __syncthreads();
+  // count (cells[c + 1] holds the count of cell c)
+  for (int v = t; v < V; v += GRID_BLOCK) {
+    const int cx = grid_cell_coord(verts[3 * (size_t)v], g.bbmin[0], g.inv_h, g.dims[0]);
+    const int cy = grid_cell_coord(verts[3 * (size_t)v + 1], g.bbmin[1], g.inv_h, g.dims[1]);
+    const int cz = grid_cell_coord(verts[3 * (size_t)v + 2], g.bbmin[2], g.inv_h, g.dims[2]);
+    atomicAdd(&cells[(cz * g.dims[1] + cy) * g.dims[0] + cx + 1], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the counts, in place: cells[c + 1] <- start of cell c
+  const int chunk = (ncell + GRID_BLOCK - 1) / GRID_BLOCK;
+  const int c0 = min(t * chunk, ncell), c1 = min(c0 + chunk, ncell);
+  uint32_t sum = 0;
+  for (int c = c0; c < c1; c++) sum += cells[c + 1];
+  s_scan[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < GRID_BLOCK; off <<= 1) {
+    const uint32_t add = t >= off ? s_scan[t - off] : 0u;
+    __syncthreads();
+    s_scan[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = s_scan[t] - sum;
+  for (int c = c0; c < c1; c++) {
+    const uint32_t n = cells[c + 1];
+    cells[c + 1] = run;
+    run += n;
+  }
+  __syncthreads();
+  // scatter: the cursor of cell c is cells[c + 1]; afterwards cells[k] = start of cell k for k = 0..ncell
+  for (int v = t; v < V; v += GRID_BLOCK) {
+    const float x = verts[3 * (size_t)v], y = verts[3 * (size_t)v + 1], z = verts[3 * (size_t)v + 2];
+    const int cx = grid_cell_coord(x, g.bbmin[0], g.inv_h, g.dims[0]);
+    const int cy = grid_cell_coord(y, g.bbmin[1], g.inv_h, g.dims[1]);
+    const int cz = grid_cell_coord(z, g.bbmin[2], g.inv_h, g.dims[2]);
+    const uint32_t pos = atomicAdd(&cells[(cz * g.dims[1] + cy) * g.dims[0] + cx + 1], 1u);
+    sorted[pos] = make_float4(x, y, z, __int_as_float(v));
+  }
+}
+
+// exact nearest vertex of q through the grid: rings of cells of growing Chebyshev radius around q's cell; after ring r every
+// unvisited vertex is farther than r*h (r whole cells lie in between), so the search stops once best < that bound.
+// (distance, index) is compared lexicographically: the lowest index wins ties, like the brute-force scan.
+__device__ __forceinline__ int grid_nearest(const char *ws, const float *q) {
+  const GridHeader *g = reinterpret_cast<const GridHeader *>(ws);
+  const uint32_t *cells = reinterpret_cast<const uint32_t *>(ws + grid_cells_offset());
+  const float4 *sorted = reinterpret_cast<const float4 *>(ws + grid_sorted_offset());
+  const float h = g->h, inv_h = g->inv_h;
+  const int d0 = g->dims[0], d1 = g->dims[1], d2 = g->dims[2];
+  const int c0 = grid_cell_coord(q[0], g->bbmin[0], inv_h, d0);
+  const int c1 = grid_cell_coord(q[1], g->bbmin[1], inv_h, d1);
+  const int c2 = grid_cell_coord(q[2], g->bbmin[2], inv_h, d2);
+  const int rmax = max(max(max(c0, d0 - 1 - c0), max(c1, d1 - 1 - c1)), max(c2, d2 - 1 - c2));
+  const float eps = 1e-3f * h;  // slack for the rounding of the cell assignment
+  float best = FLT_MAX;
+  int bid = 0x7fffffff;
+  for (int r = 0; r <= rmax; r++) {
+    if (r >= 2) {
+      const float lb = (float)(r - 1) * h - eps;
+      if (best < lb * lb) break;
+    }
+    const int z0 = max(c2 - r, 0), z1 = min(c2 + r, d2 - 1), y0 = max(c1 - r, 0), y1 = min(c1 + r, d1 - 1);
+    const int x0 = max(c0 - r, 0), x1 = min(c0 + r, d0 - 1);
+    for (int z = z0; z <= z1; z++)
+      for (int y = y0; y <= y1; y++) {
+        const int row = (z * d1 + y) * d0;
+        const bool shell = (z - c2 == r) || (c2 - z == r) || (y - c1 == r) || (c1 - y == r);
+        // shell rows: the whole x range is one contiguous run of the sorted list; inner rows: the two end cells only
+        for (int part = 0; part < (shell ? 1 : 2); part++) {
+          uint32_t b, e;
+          if (shell) {
+            b = cells[row + x0];
+            e = cells[row + x1 + 1];
+          } else {
+            const int x = part == 0 ? c0 - r : c0 + r;
+            if (x < 0 || x >= d0) continue;
+            b = cells[row + x];
+            e = cells[row + x + 1];
+          }
+          for (uint32_t i = b; i < e; i++) {
+            const float4 v = sorted[i];
+            const float d = sqdist_exact(v.x, v.y, v.z, q);
+            const int id = __float_as_int(v.w);
+            if (d < best || (d == best && id < bid)) {
+              best = d;
+              bid = id;
+            }
+          }
+        }
+      }
+  }
+  return bid;
+}
+
 struct LbsArgs {
   int P, V;
   const float *query, *normals, *smpl_verts, *weights, *lbs_offsets, *A_big, *A_pose, *off_big, *off_shape, *off_pose, *R, *Th;
   int *vert_ids;
   float *bweights, *smpl_pts, *world_pts, *transforms, *translation, *world_normals;
+  const char *grid;  // vertex grid workspace (GRID variant)
 };
 
 __device__ __forceinline__ void inv3(const float *m, float *o) {
@@ -93,8 +270,9 @@ __device__ __forceinline__ void blend_A(const float *bw, const float *sA, float 
     for (int k = 0; k < 12; k++) out[k] += bw[j] * sA[16 * j + k];
 }
 
+template <bool GRID>
 __global__ __launch_bounds__(LBS_BLOCK) void lbs_forward_kernel(const LbsArgs a) {
-  __shared__ float svx[VTILE], svy[VTILE], svz[VTILE];
+  __shared__ float svx[GRID ? 1 : VTILE], svy[GRID ? 1 : VTILE], svz[GRID ? 1 : VTILE];
   __shared__ float sAb[NJ * 16], sAp[NJ * 16];
   const int p = blockIdx.x * LBS_BLOCK + threadIdx.x;
   const bool live = p < a.P;
@@ -111,7 +289,11 @@ __global__ __launch_bounds__(LBS_BLOCK) void lbs_forward_kernel(const LbsArgs a)
   // ---- nearest vertex (k = 1, squared Euclidean distance, first minimum wins)
   float best = FLT_MAX;
   int bid = 0;
-  for (int v0 = 0; v0 < a.V; v0 += VTILE) {
+  if (GRID) {
+    __syncthreads();  // sAb / sAp
+    if (live) bid = grid_nearest(a.grid, q);
+  }
+  for (int v0 = 0; !GRID && v0 < a.V; v0 += VTILE) {
     __syncthreads();
     const int cnt = min(VTILE, a.V - v0);
     for (int i = threadIdx.x; i < cnt; i += LBS_BLOCK) {
@@ -122,8 +304,7 @@ __global__ __launch_bounds__(LBS_BLOCK) void lbs_forward_kernel(const LbsArgs a)
     __syncthreads();
     if (live) {
       for (int i = 0; i < cnt; i++) {
-        const float dx = svx[i] - q[0], dy = svy[i] - q[1], dz = svz[i] - q[2];
-        const float d = dx * dx + dy * dy + dz * dz;
+        const float d = sqdist_exact(svx[i], svy[i], svz[i], q);
         if (d < best) {
           best = d;
           bid = v0 + i;
@@ -362,8 +543,37 @@ int gsr_lbs_forward(int P, int V, const float *query, const float *normals, cons
   if (P == 0) return GSR_OK;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   gsr::LbsArgs a = {P, V, query, normals, smpl_verts, weights, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th,
-                    vert_ids, bweights, smpl_pts, world_pts, transforms, translation, world_normals};
-  hipLaunchKernelGGL(gsr::lbs_forward_kernel, dim3((P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK), dim3(gsr::LBS_BLOCK), 0, stream, a);
+                    vert_ids, bweights, smpl_pts, world_pts, transforms, translation, world_normals, nullptr};
+  hipLaunchKernelGGL(gsr::lbs_forward_kernel<false>, dim3((P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK), dim3(gsr::LBS_BLOCK), 0,
+                     stream, a);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
+size_t gsr_lbs_workspace_bytes(int V) { return V > 0 ? gsr::grid_workspace_bytes(V) : 0; }
+
+int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals, const float *smpl_verts, const float *weights,
+                         const float *lbs_offsets, const float *A_big, const float *A_pose, const float *off_big,
+                         const float *off_shape, const float *off_pose, const float *R, const float *Th, int *vert_ids,
+                         float *bweights, float *smpl_pts, float *world_pts, float *transforms, float *translation,
+                         float *world_normals, char *workspace, size_t workspace_bytes, gsr_stream_t stream_) {
+  if (P < 0 || V <= 0 || (P > 0 && (!query || !smpl_verts || !weights || !A_big || !A_pose || !off_big || !off_shape ||
+                                    !off_pose || !R || !Th || !world_pts))) {
+    gsr::set_error("gsr_lbs_forward_grid: bad arguments");
+    return GSR_EINVAL;
+  }
+  if (P == 0) return GSR_OK;
+  if (!workspace || workspace_bytes < gsr::grid_workspace_bytes(V) || reinterpret_cast<size_t>(workspace) % 16 != 0) {
+    gsr::set_error("gsr_lbs_forward_grid: workspace of %zu bytes (16-byte aligned) required, got %zu",
+                   gsr::grid_workspace_bytes(V), workspace_bytes);
+    return GSR_EINVAL;
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(gsr::lbs_grid_build_kernel, dim3(1), dim3(gsr::GRID_BLOCK), 0, stream, V, smpl_verts, workspace);
+  gsr::LbsArgs a = {P, V, query, normals, smpl_verts, weights, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th,
+                    vert_ids, bweights, smpl_pts, world_pts, transforms, translation, world_normals, workspace};
+  hipLaunchKernelGGL(gsr::lbs_forward_kernel<true>, dim3((P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK), dim3(gsr::LBS_BLOCK), 0,
+                     stream, a);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
 }

@@ -76,6 +76,9 @@ def shape_offsets(smpl, shapes):
     return torch.matmul(sd, shapes.reshape(-1, 1)).squeeze(-1)
 
 
+NEAREST_VERTEX_SEARCH = "grid"  # "grid" (uniform vertex grid, default) or "brute"; identical results
+
+
 class _LBSDeform(torch.autograd.Function):
     @staticmethod
     def forward(ctx, query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights):
@@ -95,11 +98,16 @@ class _LBSDeform(torch.autograd.Function):
         transforms = torch.empty((P, 3, 3), dtype=f32, device=dev)
         translation = torch.empty((P, 3), dtype=f32, device=dev)
         world_normals = torch.empty((P, 3), dtype=f32, device=dev) if normals is not None else None
+        args = (P, V, ptr(query_c), ptr(normals_c), ptr(sv), ptr(w), ptr(loff), ptr(A_big_c), ptr(A_pose_c), ptr(ob), ptr(os_),
+                ptr(op), ptr(R_c), ptr(Th_c), ptr(vert_ids), ptr(bweights), ptr(smpl_pts), ptr(world_pts), ptr(transforms),
+                ptr(translation), ptr(world_normals))
         with torch.cuda.device(dev):
-            check(lib.gsr_lbs_forward(P, V, ptr(query_c), ptr(normals_c), ptr(sv), ptr(w), ptr(loff), ptr(A_big_c), ptr(A_pose_c),
-                                      ptr(ob), ptr(os_), ptr(op), ptr(R_c), ptr(Th_c), ptr(vert_ids), ptr(bweights),
-                                      ptr(smpl_pts), ptr(world_pts), ptr(transforms), ptr(translation), ptr(world_normals),
-                                      torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_forward")
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if NEAREST_VERTEX_SEARCH == "grid":
+                ws = torch.empty((lib.gsr_lbs_workspace_bytes(V),), dtype=torch.uint8, device=dev)
+                check(lib.gsr_lbs_forward_grid(*args, ptr(ws), ws.numel(), stream), "gsr_lbs_forward_grid")
+            else:
+                check(lib.gsr_lbs_forward(*args, stream), "gsr_lbs_forward")
         ctx.save_for_backward(query_c, normals_c, loff, A_big_c, A_pose_c, ob, os_, op, R_c, vert_ids, w)
         ctx.shapes = (A_pose.shape, off_pose.shape, V)
         ctx.mark_non_differentiable(vert_ids, bweights, smpl_pts, translation)

@@ -142,3 +142,48 @@ def test_lbs_backward_matches_autograd(oracle, with_offsets):
     util.assert_close("d_off_pose", ho.grad.cpu().numpy(), ro.grad.numpy(), tol=1e-4)
     if with_offsets:
         util.assert_close("d_lbs_offsets", hl.grad.cpu().numpy(), rl.grad.numpy(), tol=1e-4)
+
+
+def _vertex_ids(lbs, search, query, verts, c):
+    d = util.to_dev
+    old = lbs.NEAREST_VERTEX_SEARCH
+    lbs.NEAREST_VERTEX_SEARCH = search
+    try:
+        V = verts.shape[0]
+        w = np.full((V, 24), 1.0 / 24, np.float32)
+        z = np.zeros((V, 3), np.float32)
+        out = lbs.lbs_deform(d(query), None, None, d(c["A_big"]), d(c["A_pose"]), d(z), d(z), d(z), d(c["R"]), d(c["Th"]), d(verts), d(w))
+        return out["vert_ids"].cpu().numpy()
+    finally:
+        lbs.NEAREST_VERTEX_SEARCH = old
+
+
+@pytest.mark.parametrize("case", ["near", "far_outside", "duplicates", "coincident", "planar", "single", "clusters"])
+def test_nearest_vertex_grid_equals_brute_and_oracle(oracle, case):
+    """The grid search must return the brute-force answer bit for bit (lowest index on ties), also for queries far outside
+    the vertex bounding box and for degenerate vertex clouds."""
+    from mygauhuman_amd import lbs
+    c = make_case(oracle, 700, 10, 3, False)
+    rng = np.random.default_rng(11)
+    V, P = 3000, 5000
+    verts = (rng.uniform(-1, 1, (V, 3)) * np.array([0.9, 0.9, 0.15])).astype(np.float32)
+    query = (verts[rng.integers(0, V, P)] + rng.normal(0, 0.02, (P, 3))).astype(np.float32)
+    if case == "far_outside":
+        query = (rng.normal(0, 1, (P, 3)) * 5).astype(np.float32)
+    elif case == "duplicates":   # every vertex appears four times; queries sit exactly on vertices
+        verts = np.concatenate([verts[:750]] * 4).astype(np.float32)
+        query = verts[rng.integers(0, V, P)].copy()
+    elif case == "coincident":   # zero-extent cloud
+        verts = np.tile(np.array([[0.3, -0.2, 0.1]], np.float32), (64, 1))
+    elif case == "planar":
+        verts[:, 2] = 0.25
+    elif case == "single":
+        verts = verts[:1]
+    elif case == "clusters":     # two far-apart blobs: most cells empty, long ring walks
+        verts = np.concatenate([verts[:1500] * 0.01, verts[1500:] * 0.01 + 4.0]).astype(np.float32)
+        query = (rng.uniform(-1, 5, (P, 3))).astype(np.float32)
+    want = oracle.nearest_vertex(query, verts)
+    got_grid = _vertex_ids(lbs, "grid", query, verts, c)
+    got_brute = _vertex_ids(lbs, "brute", query, verts, c)
+    np.testing.assert_array_equal(got_brute, want)
+    np.testing.assert_array_equal(got_grid, want)
