@@ -236,6 +236,22 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
                      float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
                      float *dL_doff_pose, gsr_stream_t stream);
 
+/* SMPL pose -> joint transforms (batch size 1): rodrigues of the 24 axis-angle vectors (angle = |theta + 1e-8|), the
+ * optional pose-refinement product R_j <- R_j correct_Rs[j-1] (j >= 1), the kinematic chain and the removal of the rest
+ * pose -- scene/gaussian_model.py:894-980 (batch_rodrigues_torch, get_rigid_transformation_torch,
+ * get_transform_params_torch) and :822-825 -- in one single-wave launch.
+ *   poses[72], correct_Rs[23][9] or null, joints[24][3] (device); parents_host[24]: HOST array, parents[i] < i, entry 0
+ *   ignored.  Outputs (device): rot_mats[24][9] (may be null), A[24][16] row-major 4x4. */
+int gsr_smpl_pose_forward(const float *poses, const float *correct_Rs, const float *joints, const int *parents_host,
+                          float *rot_mats, float *A, gsr_stream_t stream);
+
+/* Adjoint of gsr_smpl_pose_forward: dL_dA[24][16] (row 3 ignored), dL_drot_mats[24][9] or null (the pose blend shapes'
+ * use of rot_mats) -> dL_dposes[72], dL_dcorrect_Rs[23][9] (null if correct_Rs is null), dL_djoints[24][3]; each output
+ * may be null and is fully written otherwise. */
+int gsr_smpl_pose_backward(const float *poses, const float *correct_Rs, const float *joints, const int *parents_host,
+                           const float *dL_dA, const float *dL_drot_mats, float *dL_dposes, float *dL_dcorrect_Rs,
+                           float *dL_djoints, gsr_stream_t stream);
+
 /* Per-frame, per-Gaussian attributes render() derives between the LBS deform and the rasterizer
  * (gaussian_renderer/__init__.py:128-198; scene/gaussian_model.py:35-42,186-190; utils/general_utils.py:64-157;
  * utils/sh_utils.py:57-117; transform.py:9-17) -- one kernel instead of the reference's torch op chain.

@@ -21,6 +21,7 @@ SOURCES = [
     ("preprocess_bwd.hip", []),
     ("lbs.hip", []),
     ("attributes.hip", []),
+    ("pose.hip", []),
     ("loss.hip", []),
     ("gsr_api.hip", []),
 ]

@@ -11,6 +11,8 @@ ops per frame and stay torch (they carry the autograd graph of the pose-refineme
 kernel forward (gsr_lbs_forward) and ONE backward (gsr_lbs_backward) behind a torch.autograd.Function, instead of
 ~40 torch kernels + KNN_CUDA + an autograd graph over [P, 24, 16] intermediates.
 """
+import ctypes as C
+
 import torch
 
 from ._lib import check, lib, ptr
@@ -57,8 +59,7 @@ def get_transform_params_torch(smpl, params, rot_mats=None, correct_Rs=None):
             nr = torch.matmul(rot_mats[:, 1:].reshape(-1, 3, 3), correct_Rs.reshape(-1, 3, 3))
             rot_mats = torch.cat([rot_mats[:, 0:1], nr.reshape(-1, rot_mats.shape[1] - 1, 3, 3)], dim=1)
     joints = torch.matmul(smpl["J_regressor"][None], v_shaped)
-    parents = smpl["kintree_table"][0]
-    A = get_rigid_transformation_torch(rot_mats, joints, parents)
+    A = get_rigid_transformation_torch(rot_mats, joints, list(parents_host(smpl)))
     return A, params["R"], params["Th"], joints
 
 
@@ -76,6 +77,73 @@ def shape_offsets(smpl, shapes):
     return torch.matmul(sd, shapes.reshape(-1, 1)).squeeze(-1)
 
 
+def parents_host(smpl):
+    """Kinematic-tree parents as a host tuple, read from the device once per SMPL dict (the reference indexes the device
+    tensor joint by joint: 23 blocking reads per chain)."""
+    cached = smpl.get("_parents_host")
+    if cached is None:
+        cached = tuple(int(v) for v in smpl["kintree_table"][0].tolist())
+        smpl["_parents_host"] = cached
+    return cached
+
+
+class _SmplPose(torch.autograd.Function):
+    """poses [72] (+ correct_Rs [23,3,3]) + joints [24,3] -> (rot_mats [24,3,3], A [24,4,4]); csrc/pose.hip."""
+
+    @staticmethod
+    def forward(ctx, poses, correct_Rs, joints, parents):
+        if not poses.is_cuda:
+            raise RuntimeError("SMPL pose kernel: tensors must live on a HIP device (no CPU path)")
+        dev, f32 = poses.device, torch.float32
+        c = lambda t: None if t is None else t.detach().contiguous().float()  # noqa: E731
+        poses_c, cr, j = c(poses).reshape(72), c(correct_Rs), c(joints).reshape(24, 3)
+        if cr is not None:
+            cr = cr.reshape(23, 9)
+        par = (C.c_int * 24)(*parents)
+        rot = torch.empty((24, 3, 3), dtype=f32, device=dev)
+        A = torch.empty((24, 4, 4), dtype=f32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gsr_smpl_pose_forward(ptr(poses_c), ptr(cr), ptr(j), par, ptr(rot), ptr(A),
+                                            torch.cuda.current_stream(dev).cuda_stream), "gsr_smpl_pose_forward")
+        ctx.has_cr = cr is not None
+        ctx.save_for_backward(*([poses_c, j] + ([cr] if cr is not None else [])))
+        ctx.meta = (parents, poses.shape, None if correct_Rs is None else correct_Rs.shape, joints.shape)
+        return rot, A
+
+    @staticmethod
+    def backward(ctx, g_rot, g_A):
+        saved = ctx.saved_tensors
+        poses, j = saved[0], saved[1]
+        cr = saved[2] if ctx.has_cr else None
+        parents, p_shape, c_shape, j_shape = ctx.meta
+        dev, f32 = poses.device, torch.float32
+        par = (C.c_int * 24)(*parents)
+        need_p, need_c, need_j = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.has_cr, ctx.needs_input_grad[2]
+        d_p = torch.empty((72,), dtype=f32, device=dev) if need_p else None
+        d_c = torch.empty((23, 9), dtype=f32, device=dev) if need_c else None
+        d_j = torch.empty((24, 3), dtype=f32, device=dev) if need_j else None
+        g_A = torch.zeros((24, 4, 4), dtype=f32, device=dev) if g_A is None else g_A.contiguous().float()
+        g_rot = None if g_rot is None else g_rot.contiguous().float()
+        with torch.cuda.device(dev):
+            check(lib.gsr_smpl_pose_backward(ptr(poses), ptr(cr), ptr(j), par, ptr(g_A), ptr(g_rot), ptr(d_p), ptr(d_c), ptr(d_j),
+                                             torch.cuda.current_stream(dev).cuda_stream), "gsr_smpl_pose_backward")
+        return (None if d_p is None else d_p.view(p_shape), None if d_c is None else d_c.view(c_shape),
+                None if d_j is None else d_j.view(j_shape), None)
+
+
+def smpl_pose_transforms(smpl, params, correct_Rs=None):
+    """HIP counterpart of batch_rodrigues + get_transform_params_torch for batch size 1:
+    returns (A [1,24,4,4], rot_mats [1,24,3,3], joints [1,24,3])."""
+    betas = params["shapes"]
+    V = smpl["v_template"].shape[0]
+    sd = smpl["shapedirs"][..., :betas.shape[-1]]
+    v_shaped = smpl["v_template"] + torch.matmul(sd.reshape(V * 3, -1), betas.reshape(-1, 1).float()).view(V, 3)
+    joints = torch.matmul(smpl["J_regressor"], v_shaped)
+    rot, A = _SmplPose.apply(params["poses"], correct_Rs, joints, parents_host(smpl))
+    return A[None], rot[None], joints[None]
+
+
+POSE_CHAIN = "hip"              # "hip" (csrc/pose.hip, default) or "torch" (the reference's op chain); same results to fp32 rounding
 NEAREST_VERTEX_SEARCH = "grid"  # "grid" (uniform vertex grid, default) or "brute"; identical results
 
 
@@ -149,18 +217,22 @@ def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_we
     (= self.SMPL_NEUTRAL as device tensors) and the same 6-tuple
     (smpl_src_pts[1,P,3], world_src_pts[1,P,3], bweights[1,P,24], transforms[1,P,3,3], translation|None, world_normals)."""
     assert query_pts.shape[0] == 1, "batch size 1 (like every call site of the reference)"
-    # big pose -> T pose
-    A_big, _, _, _ = get_transform_params_torch(smpl, t_params)
-    rot_big = batch_rodrigues(t_params["poses"].view(-1, 3)).view(1, -1, 3, 3)
+    if POSE_CHAIN == "hip":
+        # big pose -> T pose, T pose -> target pose: one single-wave kernel each (csrc/pose.hip)
+        A_big, rot_big, _ = smpl_pose_transforms(smpl, t_params)
+        A_pose, rot_mats, _ = smpl_pose_transforms(smpl, params, correct_Rs)
+        R, Th = params["R"], params["Th"]
+    else:  # the reference's torch chain (kept as the fp32 reference of the pose kernel)
+        A_big, _, _, _ = get_transform_params_torch(smpl, t_params)
+        rot_big = batch_rodrigues(t_params["poses"].view(-1, 3)).view(1, -1, 3, 3)
+        rot_mats = batch_rodrigues(params["poses"].view(-1, 3)).view(1, -1, 3, 3)
+        if correct_Rs is not None:
+            nr = torch.matmul(rot_mats[:, 1:].reshape(-1, 3, 3), correct_Rs.reshape(-1, 3, 3)).reshape(-1, rot_mats.shape[1] - 1, 3, 3)
+            rot_mats = torch.cat([rot_mats[:, 0:1], nr], dim=1)
+        A_pose, R, Th, _ = get_transform_params_torch(smpl, params, rot_mats=rot_mats)
     off_big = pose_offsets(smpl, rot_big)
     off_shape = shape_offsets(smpl, params["shapes"].to(query_pts.device))
-    # T pose -> target pose
-    rot_mats = batch_rodrigues(params["poses"].view(-1, 3)).view(1, -1, 3, 3)
-    if correct_Rs is not None:
-        nr = torch.matmul(rot_mats[:, 1:].reshape(-1, 3, 3), correct_Rs.reshape(-1, 3, 3)).reshape(-1, rot_mats.shape[1] - 1, 3, 3)
-        rot_mats = torch.cat([rot_mats[:, 0:1], nr], dim=1)
     off_pose = pose_offsets(smpl, rot_mats)
-    A_pose, R, Th, _ = get_transform_params_torch(smpl, params, rot_mats=rot_mats)
     o = lbs_deform(query_pts[0], None if normals is None else normals[0], None if lbs_weights is None else lbs_weights[0],
                    A_big[0], A_pose[0], off_big, off_shape, off_pose, R.reshape(3, 3), Th.reshape(-1)[:3], t_vertices[0],
                    smpl["weights"])

@@ -187,3 +187,49 @@ def test_nearest_vertex_grid_equals_brute_and_oracle(oracle, case):
     got_brute = _vertex_ids(lbs, "brute", query, verts, c)
     np.testing.assert_array_equal(got_brute, want)
     np.testing.assert_array_equal(got_grid, want)
+
+
+@pytest.mark.parametrize("with_correct", [False, True])
+def test_smpl_pose_kernel_matches_torch_chain(oracle, with_correct):
+    """csrc/pose.hip against the reference's op chain (lbs.batch_rodrigues + get_rigid_transformation_torch) evaluated in
+    float64 with autograd: A, rot_mats and the gradients w.r.t. poses, correct_Rs and joints.  Tolerance 1e-4 (fp32)."""
+    from mygauhuman_amd import lbs
+    rng = np.random.default_rng(21)
+    dev = torch.device("cuda:0")
+    poses = torch.tensor(rng.normal(0, 0.4, (1, 72)), dtype=torch.float32, device=dev, requires_grad=True)
+    joints = torch.tensor(rng.normal(0, 0.3, (24, 3)), dtype=torch.float32, device=dev, requires_grad=True)
+    cr = None
+    if with_correct:
+        cr_np = np.stack([np.eye(3) + rng.normal(0, 0.05, (3, 3)) for _ in range(23)])
+        cr = torch.tensor(cr_np, dtype=torch.float32, device=dev, requires_grad=True)
+    wA = torch.tensor(rng.normal(0, 1, (24, 4, 4)), dtype=torch.float32, device=dev)
+    wR = torch.tensor(rng.normal(0, 1, (24, 3, 3)), dtype=torch.float32, device=dev)
+    parents = tuple(int(v) for v in PARENTS)
+
+    rot, A = lbs._SmplPose.apply(poses, cr, joints, parents)
+    ((A * wA).sum() + (rot * wR).sum()).backward()
+    got = dict(A=A.detach(), rot=rot.detach(), d_poses=poses.grad.clone(), d_joints=joints.grad.clone(),
+               d_cr=None if cr is None else cr.grad.clone())
+
+    p64 = poses.detach().double().requires_grad_(True)
+    j64 = joints.detach().double().requires_grad_(True)
+    c64 = None if cr is None else cr.detach().double().requires_grad_(True)
+    rot64 = lbs.batch_rodrigues(p64.view(-1, 3)).view(1, 24, 3, 3)
+    if c64 is not None:
+        rot64 = torch.cat([rot64[:, 0:1], torch.matmul(rot64[0, 1:], c64)[None]], dim=1)
+    A64 = lbs.get_rigid_transformation_torch(rot64, j64[None], list(parents))
+    ((A64[0] * wA.double()).sum() + (rot64[0] * wR.double()).sum()).backward()
+
+    def close(a, b, name):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a.double() - b).abs().max()) / scale
+        assert err < 1e-4, (name, err)
+    close(got["A"], A64[0].detach(), "A")
+    close(got["rot"], rot64[0].detach(), "rot_mats")
+    close(got["d_poses"], p64.grad, "d_poses")
+    close(got["d_joints"], j64.grad, "d_joints")
+    if cr is not None:
+        close(got["d_cr"], c64.grad, "d_correct_Rs")
+    assert torch.equal(A[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev).expand(24, 4))
+    with pytest.raises(RuntimeError):
+        lbs._SmplPose.apply(poses, cr, joints, (0,) + tuple(range(1, 24)))  # parents[1] = 1 does not precede joint 1

@@ -37,7 +37,7 @@ def main(P=200_000, V=6890, W=1024, H=1024):
     bp = dict(poses=d(big[None]), shapes=d(np.zeros((1, 10), np.float32)), R=d(np.eye(3, dtype=np.float32)), Th=d(np.zeros((1, 3), np.float32)))
     cam = cameras.ViewCamera(cam_np, "cuda", sp, bp, d(vt))
     bg = torch.zeros(3, device="cuda")
-    for sep in (False, True):
+    for sep in ((False,) if os.environ.get("PROFILE") else (False, True)):
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep)
 
         def step():
@@ -62,7 +62,8 @@ def main(P=200_000, V=6890, W=1024, H=1024):
                 for _ in range(3):
                     step()
                 torch.cuda.synchronize()
-            print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=35, max_name_column_width=60), flush=True)
+            print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60), flush=True)
+            print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60), flush=True)
         print(f"render() fwd+bwd, P={P}, {W}x{H}, visible={int((o['radii'] > 0).sum())}: "
               f"{'seven passes' if sep else 'fused'}: {dt:.2f} ms/frame", flush=True)
 
