@@ -123,7 +123,9 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     if (CE > 0) {
 #pragma unroll
       for (int c = 0; c < CE; c++) {
-        dxp[c] = inside ? a.dL_dextra_pix[(size_t)c * plane + p] : 0.f;
+        // colour triples whose image received no gradient (mask bit clear) are never read and cost nothing below
+        const bool on = (a.extra_mask >> (c / 3)) & 1u;
+        dxp[c] = (on && inside) ? a.dL_dextra_pix[(size_t)c * plane + p] : 0.f;
         bgd += (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2)) * dxp[c];
       }
     }
@@ -208,7 +210,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
                 float e = g1.w * dpix0[s] + g2.x * dpix1[s] + g2.y * dpix2[s] + g1.z * ddep[s] + dalp[s];
                 if (CE > 0) {
 #pragma unroll
-                  for (int c = 0; c < CE; c++) e += s_x[(g + u) * CE + c] * dxp[c];
+                  for (int t = 0; t < CE / 3; t++)
+                    if ((a.extra_mask >> t) & 1u) {  // wave-uniform
+#pragma unroll
+                      for (int c = 3 * t; c < 3 * t + 3; c++) e += s_x[(g + u) * CE + c] * dxp[c];
+                    }
                   wk[u] = w;
                 }
                 const float dL_dalpha = Tn * e - (X[s] + Tb[s]) * rc;
@@ -262,18 +268,24 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
         } else {
           // extra colour gradients: columns 9..15 ride in the first atomic, 16..(9+CE-1) in a second one
           float v1 = 0.f;
+          v = kcol < NACC ? v : 0.f;
 #pragma unroll
-          for (int c = 0; c < CE; c++) {
-            const float r = row16_sum(fold16(fold32(wk[0] * dxp[c], wk[1] * dxp[c]), fold32(wk[2] * dxp[c], wk[3] * dxp[c])));
-            const int col = NACC + c;
-            if (col < 16)
-              v = (kcol == col) ? r : v;
-            else
-              v1 = (kcol == col - 16) ? r : v1;
-          }
+          for (int t = 0; t < CE / 3; t++)
+            if ((a.extra_mask >> t) & 1u) {  // wave-uniform
+#pragma unroll
+              for (int c = 3 * t; c < 3 * t + 3; c++) {
+                const float r = row16_sum(fold16(fold32(wk[0] * dxp[c], wk[1] * dxp[c]), fold32(wk[2] * dxp[c], wk[3] * dxp[c])));
+                const int col = NACC + c;
+                if (col < 16)
+                  v = (kcol == col) ? r : v;
+                else
+                  v1 = (kcol == col - 16) ? r : v1;
+              }
+            }
           if (row_live) {
-            atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], v);
-            if (kcol < NACC + CE - 16) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + 16 + kcol], v1);
+            // columns 9..15 = channels 0..6 (triples 0, 1 and the first channel of 2); 16.. = the rest
+            if (kcol < NACC || (a.extra_mask & 7u)) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], v);
+            if ((a.extra_mask >> 2) && kcol < NACC + CE - 16) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + 16 + kcol], v1);
           }
         }
       }

@@ -198,6 +198,7 @@ struct BlendBwdArgs {
   const float *extra;          // [P][CE]
   int CE;
   const float *dL_dextra_pix;  // [CE][H][W]
+  uint32_t extra_mask;         // bit t: colour triple t (channels 3t..3t+2) has an incoming gradient
 };
 int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream);
 

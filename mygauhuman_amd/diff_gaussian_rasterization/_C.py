@@ -93,12 +93,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,
-                                 debug, out=None, extra=None, dL_dout_extra=None):
+                                 debug, out=None, extra=None, dL_dout_extra=None, extra_group_mask=0x3F):
     """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207).
 
     `out` (extension, keyword only in practice): dict name -> preallocated contiguous float32 tensor for any of
     means3D / sh / opacity / scales / rotations / cov3D / colors / means2D; the view-parallel trainer passes views of
-    one flat all-reduce bucket so gradients are produced in place."""
+    one flat all-reduce bucket so gradients are produced in place.
+    `extra`, `dL_dout_extra` [18,H,W], `extra_group_mask` (extension): the fused multi-feature blend; bit t of the mask
+    says that colour triple t has a gradient (planes of the other triples are not read)."""
     dev = means3D.device
     P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
@@ -146,7 +148,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 ptr(dL_dout_alpha), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
-                ptr(extra), 0 if extra is None else _lib.N_EXTRA, ptr(dL_dout_extra),
+                ptr(extra), 0 if extra is None else _lib.N_EXTRA, ptr(dL_dout_extra), int(extra_group_mask) & 0x3F,
                 None if dL_dextra is None else dL_dextra.data_ptr(), _stream(dev))
         check(rc, "gsr_rasterize_backward")
     if extra is not None:

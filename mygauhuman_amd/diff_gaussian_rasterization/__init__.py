@@ -100,22 +100,36 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
                                      cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
                                      rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, extra=extra)
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra = out
+        ctx.set_materialize_grads(False)  # untouched images arrive as None in backward, not as zero tensors
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
                               imgBuffer, alpha, extra)
-        return color, radii, depth, alpha, out_extra
+        # six separate outputs (views of one [18,H,W] buffer): autograd then hands back one gradient per image -- None for
+        # images the loss never touched -- instead of materialising a full 18-plane gradient per slice
+        return (color, radii, depth, alpha) + tuple(out_extra[3 * i:3 * i + 3] for i in range(N_EXTRA // 3))
 
     @staticmethod
-    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha, grad_extra):
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha, *grad_feats):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha,
          extra) = ctx.saved_tensors
+        H, W = alpha.shape[-2], alpha.shape[-1]
+        grad_extra = torch.empty((N_EXTRA, H, W), dtype=torch.float32, device=alpha.device)
+        mask = 0
+        for i, g in enumerate(grad_feats):
+            if g is not None:
+                grad_extra[3 * i:3 * i + 3].copy_(g)
+                mask |= 1 << i
+        grad_out_color = torch.zeros((3, H, W), dtype=torch.float32, device=alpha.device) if grad_out_color is None else grad_out_color
+        grad_depth = torch.zeros_like(alpha) if grad_depth is None else grad_depth
+        grad_alpha = torch.zeros_like(alpha) if grad_alpha is None else grad_alpha
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_extra_in) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
-            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, extra=extra, dL_dout_extra=grad_extra)
+            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, extra=extra, dL_dout_extra=grad_extra,
+            extra_group_mask=mask)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_extra_in, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, None)
 
@@ -136,9 +150,9 @@ def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors
             raise Exception("rasterize_gaussians_multi takes 1 to 6 extra colour sets")
         cols = list(extra_colors) + [torch.zeros((P, 3), dtype=means3D.dtype, device=means3D.device)] * (6 - n)
         extra = torch.cat(cols, dim=1)
-    color, radii, depth, alpha, out_extra = _RasterizeGaussiansMulti.apply(
-        means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
-    return color, radii, depth, alpha, [out_extra[3 * i:3 * i + 3] for i in range(n)]
+    out = _RasterizeGaussiansMulti.apply(means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp,
+                                         raster_settings)
+    return out[0], out[1], out[2], out[3], list(out[4:4 + n])
 
 
 class GaussianRasterizer(nn.Module):

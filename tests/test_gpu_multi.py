@@ -71,6 +71,50 @@ def test_forward_multi_equals_separate_passes(mode, n_extra):
         util.assert_close("extra colour grad", ea.grad.cpu().numpy(), eb.grad.cpu().numpy(), tol=1e-4, max_bad_frac=1e-4)
 
 
+@pytest.mark.parametrize("used", [(0, 5), (2,), (3, 4), (), (1, 2, 3, 4, 5)])
+@pytest.mark.parametrize("with_color", [True, False])
+def test_forward_multi_partial_loss_masks_untouched_images(used, with_color):
+    """Only some of the seven images enter the loss: autograd hands None for the others, the backward kernel gets a group
+    mask and must produce the same gradients as separate passes (zeros for the untouched colour sets)."""
+    from mygauhuman_amd.diff_gaussian_rasterization import GaussianRasterizer
+    P, W, H = 4000, 130, 90
+    cam, g = util.make_scene(P, W, H, 33, 3, 0.03, 0.02)
+    bg = np.array([0.2, 0.5, 0.7], np.float32)
+    rast = GaussianRasterizer(_settings(cam, bg, 3))
+
+    def leaves():
+        rng = np.random.default_rng(8)
+        t = {k: util.to_dev(v).requires_grad_(True) for k, v in g.items() if isinstance(v, np.ndarray)}
+        t["extras"] = [util.to_dev(rng.uniform(0, 1, (P, 3)).astype(np.float32)).requires_grad_(True) for _ in range(6)]
+        t["means2D"] = torch.zeros((P, 3), device="cuda", requires_grad=True)
+        return t
+
+    a, b = leaves(), leaves()
+    kw = lambda t: dict(colors_precomp=t["colors"], cov3D_precomp=t["cov3D"])  # noqa: E731
+    color, radii, depth, alpha, feats = rast.forward_multi(means3D=a["means3D"], means2D=a["means2D"], opacities=a["opacities"],
+                                                           extra_colors=a["extras"], **kw(a))
+    c0, r0, d0, a0 = rast(means3D=b["means3D"], means2D=b["means2D"], opacities=b["opacities"], **kw(b))
+    sep = [rast(means3D=b["means3D"], means2D=b["means2D"], opacities=b["opacities"], colors_precomp=e, cov3D_precomp=b["cov3D"])[0]
+           for e in b["extras"]]
+    wr = np.random.default_rng(9)
+    ws = [util.to_dev(wr.normal(0, 1, (3, H, W)).astype(np.float32)) for _ in range(7)]
+    la = (depth * 0.0).sum() + sum((feats[i] * ws[1 + i]).sum() for i in used)
+    lb = (d0 * 0.0).sum() + sum((sep[i] * ws[1 + i]).sum() for i in used)
+    if with_color:
+        la = la + (color * ws[0]).sum()
+        lb = lb + (c0 * ws[0]).sum()
+    la.backward()
+    lb.backward()
+    for k in ("means3D", "means2D", "opacities", "colors", "cov3D"):
+        gb = b[k].grad if b[k].grad is not None else torch.zeros_like(b[k])
+        util.assert_close(k, a[k].grad.cpu().numpy(), gb.cpu().numpy(), tol=1e-4, max_bad_frac=1e-4)
+    for i, (ea, eb) in enumerate(zip(a["extras"], b["extras"])):
+        if i in used:
+            util.assert_close("extra colour grad", ea.grad.cpu().numpy(), eb.grad.cpu().numpy(), tol=1e-4, max_bad_frac=1e-4)
+        else:
+            assert float(ea.grad.abs().max()) == 0.0
+
+
 def test_render_fused_equals_seven_passes(oracle):
     from mygauhuman_amd.gaussian_renderer import render
     from tests.test_gpu_render import _human_scene

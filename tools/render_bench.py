@@ -12,6 +12,8 @@ from mygauhuman_amd import cameras  # noqa: E402
 from mygauhuman_amd.gaussian_renderer import render  # noqa: E402
 from mygauhuman_amd.scene_model import HumanGaussianModel  # noqa: E402
 
+ALL_KEYS = ("render", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis")
+PHASE1_KEYS = ("render", "render_alpha", "normal", "render_axis")  # the images train.py:256-286 puts in the loss before the PBR phase
 PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], np.int64)
 
 
@@ -37,14 +39,14 @@ def main(P=200_000, V=6890, W=1024, H=1024):
     bp = dict(poses=d(big[None]), shapes=d(np.zeros((1, 10), np.float32)), R=d(np.eye(3, dtype=np.float32)), Th=d(np.zeros((1, 3), np.float32)))
     cam = cameras.ViewCamera(cam_np, "cuda", sp, bp, d(vt))
     bg = torch.zeros(3, device="cuda")
-    for sep in ((False,) if os.environ.get("PROFILE") else (False, True)):
+    for sep, keys in ((False, ALL_KEYS),) if os.environ.get("PROFILE") else ((False, ALL_KEYS), (False, PHASE1_KEYS), (True, ALL_KEYS)):
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep)
 
         def step():
             for p in model.parameters():
                 p.grad = None
             o = render(1, cam, model, pipe, bg)
-            loss = sum(o[k].mean() for k in ("render", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis"))
+            loss = sum(o[k].mean() for k in keys)
             loss.backward()
             return o
         for _ in range(3):
@@ -65,7 +67,7 @@ def main(P=200_000, V=6890, W=1024, H=1024):
             print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60), flush=True)
             print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60), flush=True)
         print(f"render() fwd+bwd, P={P}, {W}x{H}, visible={int((o['radii'] > 0).sum())}: "
-              f"{'seven passes' if sep else 'fused'}: {dt:.2f} ms/frame", flush=True)
+              f"{'seven passes' if sep else 'fused'}, loss over {len(keys)} images: {dt:.2f} ms/frame", flush=True)
 
 
 if __name__ == "__main__":
