@@ -37,6 +37,18 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x128>(v);  // row_ror 8
   return v;
 }
+// sum over the 8 lanes (lx = lane & 7) of each half row; both halves are reduced independently
+__device__ __forceinline__ float half8_sum(float v) {
+  v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);  // row_half_mirror: lane l <-> 7 - l inside each half (the quads are uniform by now)
+  return v;
+}
+// lower half row <- a summed over both halves, upper half row <- b summed over both halves (one DPP for two values)
+__device__ __forceinline__ float pack_halves(float a, float b, bool upper) {
+  const float keep = upper ? b : a, send = upper ? a : b;
+  return keep + dpp_f<0x128>(send);  // row_ror 8
+}
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // lanes 0-31: sum over the wave of a; lanes 32-63: sum over the wave of b (both still spread over 32 lanes)
 __device__ __forceinline__ float fold32(float a, float b) {
@@ -74,6 +86,12 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   static_assert(CE == 0 || SLOTS == 1, "feature channels are only built for one pixel per lane");
   constexpr int WPT = 4 / SLOTS;
   constexpr int ROWF = CE > 0 ? GROWX : GROW;
+  // SEP: separable reduction (one pixel per lane, lane = 8 ly + lx): per lane only sum r, sum r dy, sum r dy^2 and the three
+  // colour sums are kept (6 values instead of 9); after the folds one row_ror-8 step turns them into COLUMN sums, the
+  // x-weights (dx is a function of lx alone) are applied there, two values are packed into the two half rows, and three DPP
+  // steps over 8 lanes finish: 18 permlane swaps + 19 DPP per four Gaussians instead of 27 + 36.
+  constexpr bool SEP = (SLOTS == 1 && RED == 0);
+  constexpr int NA = SEP ? 6 : NACC;
   __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
@@ -139,6 +157,16 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   const int skip = n - maxlast;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int row = (int)(lane >> 4), kcol = (int)(lane & 15);
+  // separable reduction: which gradient-row column this lane feeds in the first / second atomic instruction (0xFF = none)
+  const bool upper = (lane & 8u) != 0;
+  const int jj = (int)(lane & 7u);
+  constexpr uint64_t COLA_LO = 0x080F0C0906050200ull, COLA_UP = 0x0B0E0D0A07010403ull;  // bytes jj = 0..7
+  constexpr uint64_t COLB_LO = 0xFFFFFF1411181512ull, COLB_UP = 0xFFFF1A1710191613ull;
+  const int colA = (int)(((upper ? COLA_UP : COLA_LO) >> (8 * jj)) & 0xFF);
+  const int colB = (int)(((upper ? COLB_UP : COLB_LO) >> (8 * jj)) & 0xFF);
+  // an extra-colour column is live only if its triple is in the mask
+  const bool onA = colA < NACC || ((a.extra_mask >> ((colA - NACC) / 3)) & 1u);
+  const bool onB = colB != 0xFF && ((a.extra_mask >> ((colB - NACC) / 3)) & 1u);
 
   for (int base = skip; base < n; base += WAVE) {
     // ---- fetch 64 entries (from the back), cull, compact into LDS in back-to-front order
@@ -180,14 +208,14 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     for (int g = 0; g < cnt; g += 4) {
-      float acc[4][NACC];
+      float acc[4][NA];
       float wk[4];  // blending weight of this lane's pixel for each of the four Gaussians (0 if not hit)
       uint32_t anyhit = 0;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         wk[u] = 0.f;
 #pragma unroll
-        for (int k = 0; k < NACC; k++) acc[u][k] = 0.f;
+        for (int k = 0; k < NA; k++) acc[u][k] = 0.f;
         if (g + u < cnt) {  // wave-uniform
           const float4 g0 = s0[g + u];
           const float4 g1 = s1[g + u];
@@ -222,23 +250,99 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
                 T[s] = Tn;
                 // moments of r = G * dL_dalpha over the pixels; preprocess_bwd.hip turns them into dL_dmean2D / dL_dconic
                 const float r = G * dL_dalpha;
-                const float rx = r * dx, ry = r * dy;
-                acc[u][0] += rx;
-                acc[u][1] += ry;
-                acc[u][2] += rx * dx;
-                acc[u][3] += rx * dy;
-                acc[u][4] += ry * dy;
-                acc[u][5] += r;
-                acc[u][6] += w * dpix0[s];
-                acc[u][7] += w * dpix1[s];
-                acc[u][8] += w * dpix2[s];
+                if constexpr (SEP) {
+                  // only the y-weights go in per lane; the x-weights are applied to the COLUMN sums after the folds
+                  const float ry = r * dy;
+                  acc[u][0] += r;
+                  acc[u][1] += ry;
+                  acc[u][2] += ry * dy;
+                  acc[u][3] += w * dpix0[s];
+                  acc[u][4] += w * dpix1[s];
+                  acc[u][5] += w * dpix2[s];
+                } else {
+                  const float rx = r * dx, ry = r * dy;
+                  acc[u][0] += rx;
+                  acc[u][1] += ry;
+                  acc[u][2] += rx * dx;
+                  acc[u][3] += rx * dy;
+                  acc[u][4] += ry * dy;
+                  acc[u][5] += r;
+                  acc[u][6] += w * dpix0[s];
+                  acc[u][7] += w * dpix1[s];
+                  acc[u][8] += w * dpix2[s];
+                }
               }
             }
           }
         }
       }
       if (anyhit) {  // wave-uniform
-        // four Gaussians x nine values reduced together; afterwards row 0/1/2/3 = Gaussian g+0 / g+2 / g+1 / g+3
+        const int u_of_row = ((row & 1) << 1) | (row >> 1);  // after the folds row 0/1/2/3 = Gaussian g+0 / g+2 / g+1 / g+3
+        const bool row_live = ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
+        const uint32_t gid = row_live ? s_id[g + u_of_row] : 0u;
+        if constexpr (SEP) {
+          float c[NA];
+#pragma unroll
+          for (int k = 0; k < NA; k++) c[k] = fold16(fold32(acc[0][k], acc[1][k]), fold32(acc[2][k], acc[3][k]));
+          // lane j of a row now holds the sum over ly = (j >> 3) mod 2 of column lx = j & 7
+          const float dxr = s0[g + u_of_row].x - pxf[0];  // this row's Gaussian against this lane's column
+          float qa = pack_halves(c[0], c[1], upper);       // lower: col-sum r        upper: col-sum r dy
+          float qb = qa * dxr;                             // lower: col-sum r dx     upper: col-sum r dx dy
+          const float c2 = c[2] + dpp_f<0x128>(c[2]);      // col-sum r dy^2 (used by the upper half)
+          float qc = upper ? c2 : qb * dxr;                // lower: col-sum r dx^2   upper: col-sum r dy^2
+          float ka = pack_halves(c[3], c[4], upper);       // lower: red              upper: green
+          float kb = c[5] + dpp_f<0x128>(c[5]);            // blue in both halves
+          qa = half8_sum(qa);
+          qb = half8_sum(qb);
+          qc = half8_sum(qc);
+          ka = half8_sum(ka);
+          kb = half8_sum(kb);
+          // one value per lane: jj = 0 qb, 1 qc, 2 qa, 3 ka, (7, lower) kb; colA maps (half, jj) to the gradient-row column
+          float v = qb;
+          v = jj == 1 ? qc : v;
+          v = jj == 2 ? qa : v;
+          v = jj == 3 ? ka : v;
+          if constexpr (CE == 0) {
+            v = jj == 7 ? kb : v;
+            if (row_live && colA < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + colA], v);
+          } else {
+            // extra colour sums, a triple at a time: P = (channel 3t | channel 3t+1) packed in the half rows, S = channel 3t+2
+            constexpr int NT = CE / 3;
+            float P[NT], S[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+              P[t] = 0.f;
+              S[t] = 0.f;
+              if ((a.extra_mask >> t) & 1u) {  // wave-uniform
+                float e3[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                  const float d = dxp[3 * t + j];
+                  e3[j] = fold16(fold32(wk[0] * d, wk[1] * d), fold32(wk[2] * d, wk[3] * d));
+                }
+                P[t] = half8_sum(pack_halves(e3[0], e3[1], upper));
+                S[t] = half8_sum(e3[2] + dpp_f<0x128>(e3[2]));
+              }
+            }
+            // first atomic: columns 0..15 (lower: Mx Mxx M0 K0 ch0 ch3 ch6 K2 | upper: Mxy Myy My K1 ch1 ch4 ch5 ch2)
+            v = jj == 4 ? P[0] : v;
+            v = jj == 5 ? P[1] : v;
+            v = jj == 6 ? (upper ? S[1] : P[2]) : v;
+            v = jj == 7 ? (upper ? S[0] : kb) : v;
+            // second atomic: columns 16..26 (lower: ch9 ch12 ch15 ch8 ch11 | upper: ch10 ch13 ch16 ch7 ch14 ch17)
+            float v1 = P[3];
+            v1 = jj == 1 ? P[4] : v1;
+            v1 = jj == 2 ? P[5] : v1;
+            v1 = jj == 3 ? (upper ? P[2] : S[2]) : v1;
+            v1 = jj == 4 ? (upper ? S[4] : S[3]) : v1;
+            v1 = jj == 5 ? S[5] : v1;
+            if (row_live) {
+              if (onA) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + colA], v);
+              if (onB) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + colB], v1);
+            }
+          }
+        } else {
+        // four Gaussians x nine values reduced together
         float v;
         if constexpr (RED == 0) {
           float red[NACC];
@@ -260,33 +364,8 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
           }
           v = row == 0 ? d2[0] : (row == 1 ? d2[1] : (row == 2 ? d2[2] : d2[3]));
         }
-        const int u_of_row = ((row & 1) << 1) | (row >> 1);  // 0,2,1,3
-        const bool row_live = ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
-        const uint32_t gid = row_live ? s_id[g + u_of_row] : 0u;
-        if (CE == 0) {
-          if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], v);
-        } else {
-          // extra colour gradients: columns 9..15 ride in the first atomic, 16..(9+CE-1) in a second one
-          float v1 = 0.f;
-          v = kcol < NACC ? v : 0.f;
-#pragma unroll
-          for (int t = 0; t < CE / 3; t++)
-            if ((a.extra_mask >> t) & 1u) {  // wave-uniform
-#pragma unroll
-              for (int c = 3 * t; c < 3 * t + 3; c++) {
-                const float r = row16_sum(fold16(fold32(wk[0] * dxp[c], wk[1] * dxp[c]), fold32(wk[2] * dxp[c], wk[3] * dxp[c])));
-                const int col = NACC + c;
-                if (col < 16)
-                  v = (kcol == col) ? r : v;
-                else
-                  v1 = (kcol == col - 16) ? r : v1;
-              }
-            }
-          if (row_live) {
-            // columns 9..15 = channels 0..6 (triples 0, 1 and the first channel of 2); 16.. = the rest
-            if (kcol < NACC || (a.extra_mask & 7u)) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], v);
-            if ((a.extra_mask >> 2) && kcol < NACC + CE - 16) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + 16 + kcol], v1);
-          }
+        static_assert(SEP || CE == 0, "the feature channels use the separable reduction");
+        if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], v);
         }
       }
     }
