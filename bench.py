@@ -102,6 +102,26 @@ def cpu_baseline(wl, cam, g, gt, mask, bg):
                 host_cpus=os.cpu_count())
 
 
+PMC_KERNEL = {"blend_bwd": "blend_backward_kernel<1, 0, 0>", "blend_fwd": "blend_forward_kernel<1, 0>"}
+
+
+def pmc_traffic(stage, workload):
+    """Memory-side bytes per launch of the dominant kernel.  PMC passes cannot run inside the bench, so the figure comes from
+    the newest committed summary profiles/*_pmc.csv (tools/profile_round.sh: separate rocprofv3 --pmc passes of THIS command
+    for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md) -- C3 only; else null."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))
+    if workload != "C3" or not files or stage not in PMC_KERNEL:
+        return {"traffic": None}
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"] == PMC_KERNEL[stage]:
+            return {"traffic": int(float(r["fetch_bytes_x2"]) + float(r["write_bytes"])),
+                    "traffic_source": "profiles/" + os.path.basename(files[-1]) + " (2 x FETCH_SIZE + WRITE_SIZE per launch; "
+                                      "WRITE_SIZE counts every float-atomic lane as 4 B)"}
+    return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,7 +234,7 @@ def main():
             "splatted_gaussians_per_s": round(fps * P, 1),
             "instances_per_s": round(float(Rt.item()) * a.steps / elapsed, 1),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic(dominant, a.workload),
                          "algorithmic_bytes_per_launch": int(sb[dominant]), "avg_launch_ms": round(dom_avg_ms, 5),
                          "launches_timed": int(dom_n)},
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items() if k in sb},
