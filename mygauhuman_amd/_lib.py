@@ -4,6 +4,11 @@ There is NO fallback: if the HIP library is missing or does not load, importing 
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64 / libhsa-runtime64 under torch/lib.  Import it BEFORE libgsr.so is dlopen'ed so that both
+# bind to ONE HIP runtime (the loader reuses the already loaded soname); the other order puts two runtimes in the process
+# and the second one finds "no ROCm-capable device".
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr.so")
 
@@ -24,7 +29,8 @@ Q = dict(DEPTHS=0, MEANS2D=1, CONIC_OPACITY=2, RGB=3, COV3D=4, TILES_TOUCHED=5, 
          POINT_LIST=8, KEYS_SORTED=9, RANGES=10, FINAL_T=11, N_CONTRIB=12)
 BINNING_GLOBAL_RADIX, BINNING_TILE_BUCKET = 0, 1
 N_EXTRA = 18  # extra feature channels of the fused multi-feature blend (six RGB triples)
-DEFAULT_BINNING = BINNING_GLOBAL_RADIX
+DEFAULT_BINNING = BINNING_TILE_BUCKET
+DEFAULT_TILE_CULL = 1  # tuning knob "tile_cull": exact ellipse-vs-tile culling in the tile-bucket back-end
 DEFAULT_BWD_REDUCE = 0
 
 

@@ -63,11 +63,16 @@ __device__ __forceinline__ void expand_block_instances(const GeomState &g, const
 // Variant for kernels whose per-instance work starts with a long-latency returning operation (an atomic): UNROLL
 // instances per lane are started back to back (tok = begin(...)) before any result is consumed (finish(..., tok)), so
 // UNROLL atomics per lane are in flight instead of one.
-template <int UNROLL, typename FB, typename FE>
+// TIGHT: an instance whose tile cannot receive alpha >= 1/255 from the Gaussian (exact ellipse-vs-tile test, the one the
+// blend kernels use per quadrant) is not started at all; finish() gets CULLED_INSTANCE as its token.
+constexpr uint32_t CULLED_INSTANCE = 0xFFFFFFFFu;
+template <int UNROLL, bool TIGHT, typename FB, typename FE>
 __device__ __forceinline__ void expand_block_instances_2phase(const GeomState &g, const int *radii, int P, int gx, int gy,
                                                               bool write_offsets, FB begin, FE finish) {
   __shared__ uint32_t s_incl[PRE_BLOCK];
   __shared__ uint32_t s_rect[PRE_BLOCK];  // x0 | y0 << 10 | width << 20
+  __shared__ float4 s_geo[TIGHT ? PRE_BLOCK : 1];   // x, y, conic a, conic b
+  __shared__ float2 s_geo2[TIGHT ? PRE_BLOCK : 1];  // conic c, opacity
   const int first = blockIdx.x * PRE_BLOCK;
   const int i = first + threadIdx.x;
   const uint32_t bprefix = g.block_prefix[blockIdx.x];
@@ -81,6 +86,11 @@ __device__ __forceinline__ void expand_block_instances_2phase(const GeomState &g
       int x0, y0, x1, y1;
       tile_rect(r0.x, r0.y, rad, gx, gy, x0, y0, x1, y1);
       rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
+      if (TIGHT) {
+        const float4 r1 = reinterpret_cast<const float4 *>(g.recs + i)[1];
+        s_geo[threadIdx.x] = r0;
+        s_geo2[threadIdx.x] = make_float2(r1.x, r1.y);
+      }
     }
   }
   s_incl[threadIdx.x] = incl;
@@ -110,7 +120,15 @@ __device__ __forceinline__ void expand_block_instances_2phase(const GeomState &g
         const uint32_t local = k - start;
         const uint32_t rc = s_rect[lo];
         const uint32_t w = rc >> 20, x0 = rc & 1023u, y0 = (rc >> 10) & 1023u;
-        tok[u] = begin((y0 + local / w) * (uint32_t)gx + x0 + local % w);
+        const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+        bool keep = true;
+        if (TIGHT) {
+          const float4 ge = s_geo[lo];
+          const float2 g2 = s_geo2[lo];
+          const float px0 = (float)(tx * TILE), py0 = (float)(ty * TILE);
+          keep = ellipse_hits_rect(ge.x, ge.y, ge.z, ge.w, g2.x, g2.y, px0, px0 + (float)(TILE - 1), py0, py0 + (float)(TILE - 1));
+        }
+        tok[u] = keep ? begin(ty * (uint32_t)gx + tx) : CULLED_INSTANCE;
       }
     }
 #pragma unroll

@@ -44,7 +44,7 @@ static uint32_t higher_msb(uint32_t n) {
   return msb;
 }
 
-static int g_binning_mode = GSR_BINNING_GLOBAL_RADIX;
+static int g_binning_mode = GSR_BINNING_TILE_BUCKET;
 
 // pinned host word for the one device->host read of a forward call (num_rendered, CR/rasterizer_impl.cu:283)
 static int readback_u32(const uint32_t *dev, uint32_t *out, hipStream_t stream) {
@@ -103,6 +103,7 @@ static void prof_collect() {
 
 int set_blend_forward_waves(int nw);
 int set_bucket_counter_stride(int s);
+int set_bucket_tile_cull(int on);
 int set_blend_backward_reduce(int mode);
 int set_blend_backward_waves(int nw);
 
@@ -155,6 +156,7 @@ int gsr_set_tuning(const char *key, int value) {
   if (!strcmp(key, "blend_fwd_waves")) return set_blend_forward_waves(value);
   if (!strcmp(key, "blend_bwd_waves")) return set_blend_backward_waves(value);
   if (!strcmp(key, "bucket_cstride")) return set_bucket_counter_stride(value);
+  if (!strcmp(key, "tile_cull")) return set_bucket_tile_cull(value);
   if (!strcmp(key, "blend_bwd_reduce")) return set_blend_backward_reduce(value);
   set_error("unknown tuning key %s", key);
   return GSR_EINVAL;

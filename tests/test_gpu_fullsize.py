@@ -46,17 +46,27 @@ def test_c2_forward_properties():
     cam, g = _setup(P, W, H, 0)
     bg = np.zeros(3, np.float32)
     res = {}
+    util.set_tile_cull(False)
     for mode in (_lib.BINNING_GLOBAL_RADIX, _lib.BINNING_TILE_BUCKET):
         _lib.check(_lib.lib.gsr_set_binning_mode(mode), "mode")
         f = util.hip_forward(cam, g, bg, "sh")
         res[mode] = (_check_binning(f, P, W, H), f)
     _lib.lib.gsr_set_binning_mode(_lib.DEFAULT_BINNING)
+    util.set_tile_cull(_lib.DEFAULT_TILE_CULL)
     (ka, pa, ra), fa = res[0]
     (kb, pb, rb), fb = res[1]
     np.testing.assert_array_equal(ka, kb)
     np.testing.assert_array_equal(pa, pb)
     np.testing.assert_array_equal(ra, rb)
     assert torch.equal(fa["color"], fb["color"]) and torch.equal(fa["alpha"], fb["alpha"])
+    # library default (tight tile culling): shorter lists, the SAME image bits -- culled instances never blended anything
+    ft = util.hip_forward(cam, g, bg, "sh")
+    rt = util.hip_query(ft, "RANGES").view(np.uint32).reshape(-1, 2).astype(np.int64)
+    kept = int((rt[:, 1] - rt[:, 0]).sum())
+    assert 0 < kept < fb["R"] and np.all(rt[:, 1] - rt[:, 0] <= rb[:, 1] - rb[:, 0])
+    for k in ("color", "alpha", "depth"):
+        assert torch.equal(ft[k], fb[k]), k
+    assert torch.equal(ft["radii"], fb["radii"]) and ft["R"] == fb["R"]
     a = fa["alpha"]
     assert float(a.min()) >= 0 and float(a.max()) <= 1.0 + 1e-4
     assert float(util.to_dev(util.hip_query(fa, "FINAL_T")).min()) >= 0
@@ -72,9 +82,11 @@ def test_c3_forward_backward_properties():
     for waves in (1, 2, 4):
         _lib.set_tuning("blend_fwd_waves", waves)
         _lib.set_tuning("blend_bwd_waves", waves)
-        f = util.hip_forward(cam, g, bg, "sh")
         if waves == 4:
-            _check_binning(f, P, W, H)
+            util.set_tile_cull(False)
+            _check_binning(util.hip_forward(cam, g, bg, "sh"), P, W, H)
+            util.set_tile_cull(_lib.DEFAULT_TILE_CULL)
+        f = util.hip_forward(cam, g, bg, "sh")
         color, alpha = f["color"].cpu().numpy(), f["alpha"].cpu().numpy()
         dc = (np.sign(color - gt) / color.size).astype(np.float32)
         da = (0.2 * (alpha - mask) / alpha.size).astype(np.float32)

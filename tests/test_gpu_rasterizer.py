@@ -37,13 +37,17 @@ def waves(request):
     _lib.set_tuning("blend_bwd_reduce", _lib.DEFAULT_BWD_REDUCE)
 
 
-@pytest.fixture(scope="module", params=["radix", "bucket"])
+@pytest.fixture(scope="module", params=["radix", "bucket", "bucket_tight"])
 def binning(request):
+    """radix / bucket: the reference's instance lists, bit for bit.  bucket_tight (the library default): instances whose
+    tile the Gaussian cannot reach with alpha >= 1/255 are dropped -- images and gradients unchanged, lists are sublists."""
     from mygauhuman_amd import _lib
-    _lib.check(_lib.lib.gsr_set_binning_mode(_lib.BINNING_TILE_BUCKET if request.param == "bucket" else _lib.BINNING_GLOBAL_RADIX),
+    _lib.check(_lib.lib.gsr_set_binning_mode(_lib.BINNING_GLOBAL_RADIX if request.param == "radix" else _lib.BINNING_TILE_BUCKET),
                "gsr_set_binning_mode")
+    util.set_tile_cull(request.param == "bucket_tight")
     yield request.param
     _lib.lib.gsr_set_binning_mode(_lib.DEFAULT_BINNING)
+    util.set_tile_cull(_lib.DEFAULT_TILE_CULL)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"P{c[0]}_{c[1]}x{c[2]}" for c in CASES])
@@ -61,9 +65,14 @@ def test_forward_matches_oracle(oracle, case, mode, waves, binning):
     assert f["R"] == b["R"]
     np.testing.assert_array_equal(util.hip_query(f, "TILES_TOUCHED").view(np.uint32), pre["tiles_touched"])
     np.testing.assert_array_equal(util.hip_query(f, "POINT_OFFSETS").view(np.uint32), b["offsets"])
-    np.testing.assert_array_equal(util.hip_query(f, "KEYS_SORTED").view(np.uint64), b["keys_sorted"])
-    np.testing.assert_array_equal(util.hip_query(f, "POINT_LIST").view(np.uint32), b["point_list"])
-    np.testing.assert_array_equal(util.hip_query(f, "RANGES").view(np.uint32), b["ranges"])
+    tight = binning == "bucket_tight"
+    if tight:
+        kept = util.assert_lists_are_sublists(f, b, ((W + 15) // 16) * ((H + 15) // 16))
+        assert kept <= b["R"]
+    else:
+        np.testing.assert_array_equal(util.hip_query(f, "KEYS_SORTED").view(np.uint64), b["keys_sorted"])
+        np.testing.assert_array_equal(util.hip_query(f, "POINT_LIST").view(np.uint32), b["point_list"])
+        np.testing.assert_array_equal(util.hip_query(f, "RANGES").view(np.uint32), b["ranges"])
     # ---- per-Gaussian float state: same operation order, no FMA contraction -> identical bits
     vis = pre["radii"] > 0
     np.testing.assert_array_equal(util.hip_query(f, "DEPTHS")[vis], pre["depths"][vis])
@@ -77,7 +86,10 @@ def test_forward_matches_oracle(oracle, case, mode, waves, binning):
     solid = img["fragile"] == 0
     assert solid.mean() > 0.995
     ncon = util.hip_query(f, "N_CONTRIB").view(np.uint32)
-    np.testing.assert_array_equal(ncon[solid], img["n_contrib"][solid])
+    if tight:  # positions count the shorter lists
+        assert np.all(ncon[solid] <= img["n_contrib"][solid])
+    else:
+        np.testing.assert_array_equal(ncon[solid], img["n_contrib"][solid])
     util.assert_close("final_T", util.hip_query(f, "FINAL_T"), img["final_T"], mask=solid)
     util.assert_close("color", f["color"].cpu().numpy(), img["color"], mask=np.broadcast_to(solid, (3, H, W)))
     util.assert_close("depth", f["depth"].cpu().numpy(), img["depth"], mask=solid[None])

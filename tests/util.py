@@ -83,3 +83,26 @@ def assert_close(name, got, want, tol=1e-4, mask=None, max_bad_frac=0.0):
         bad &= mask
     frac = bad.mean()
     assert frac <= max_bad_frac, f"{name}: {bad.sum()} / {bad.size} elements off; max err {err[bad].max():.3e} (scale {scale:.3e})"
+
+
+def set_tile_cull(on):
+    """Tuning knob "tile_cull" of the tile-bucket binning back-end (library default: on)."""
+    from mygauhuman_amd import _lib
+    _lib.set_tuning("tile_cull", int(bool(on)))
+
+
+def assert_lists_are_sublists(f, ref_bin, tiles):
+    """Tight tile culling: every tile's list must be a subsequence (same order) of the reference list of that tile."""
+    ranges = hip_query(f, "RANGES").view(np.uint32).reshape(-1, 2).astype(np.int64)
+    pl = hip_query(f, "POINT_LIST").view(np.uint32)
+    rr, rp = ref_bin["ranges"].astype(np.int64), ref_bin["point_list"]
+    kept = 0
+    for t in range(tiles):
+        mine = pl[ranges[t, 0]:ranges[t, 1]]
+        ref = rp[rr[t, 0]:rr[t, 1]]
+        assert len(mine) <= len(ref)
+        pos = {int(g): i for i, g in enumerate(ref)}   # a Gaussian appears at most once per tile
+        idx = [pos[int(g)] for g in mine]              # KeyError = an instance the reference does not have
+        assert all(a < b for a, b in zip(idx, idx[1:])), f"tile {t}: order differs from the reference list"
+        kept += len(mine)
+    return kept
