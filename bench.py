@@ -227,7 +227,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {wl['desc']}; S-uniform seed 0, FoV 50deg, "
                                    + ("identity camera" if world == 1 else f"{world} views/step, 1 view/GPU (cameras orbiting the scene centre in 3deg steps), RCCL all-reduce of "
-                                      f"{(step.bucket.nbytes if step else 0) / 1e6:.1f} MB gradients"),
+                                      f"{(step.bucket.nbytes if step else 0) / 1e6:.1f} MB gradients"
+                                      + (f" + all-gather of {step.compact.stride * 4 / 1e6:.1f} MB/rank (compact SH gradient)"
+                                         if (step is not None and step.compact is not None) else "")),
                        "P": P, "sh_degree": deg, "width": W, "height": H, "num_rendered_rank0": int(R),
                        "binning": "tile_bucket" if (step is not None or _lib.lib.gsr_get_binning_mode() == 1) else "global_radix",
                        "host_sync_per_step": 0 if step is not None else 1},

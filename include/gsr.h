@@ -239,6 +239,17 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
                      float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
                      float *dL_doff_pose, gsr_stream_t stream);
 
+/* Compact exchange of the SH-coefficient gradient between view-parallel ranks (extension).  For one view
+ * dL_dsh[i][k][c] = w_k(dir_i) * dL_dRGB[i][c] (dir = normalise(mean - campos); dL_dRGB zeroed on clamped channels,
+ * CR/backward.cu:40-116): ranks all-gather 12 B per Gaussian instead of all-reducing 12 M B.
+ *   gsr_sh_view_pack: packed[P][3] = dL_dcolor (the backward's dL_dcolor output of an SH-mode call) with the channels the
+ *     forward clamped set to zero; geom_buffer is that call's geometry buffer.
+ *   gsr_sh_grad_from_views: dL_dsh[P][M][3] = scale * sum_v w_k(normalise(means3D - campos_v)) * packed_v, v in fixed
+ *     order; `views` holds n_views blocks of view_stride floats: [P*3 packed | campos xyz | padding]. */
+int gsr_sh_view_pack(int P, const char *geom_buffer, const float *dL_dcolor, float *packed, gsr_stream_t stream);
+int gsr_sh_grad_from_views(int P, int sh_degree, int M, int n_views, const float *means3D, const float *views,
+                           size_t view_stride, float scale, float *dL_dsh, gsr_stream_t stream);
+
 /* SMPL pose -> joint transforms (batch size 1): rodrigues of the 24 axis-angle vectors (angle = |theta + 1e-8|), the
  * optional pose-refinement product R_j <- R_j correct_Rs[j-1] (j >= 1), the kinematic chain and the removal of the rest
  * pose -- scene/gaussian_model.py:894-980 (batch_rodrigues_torch, get_rigid_transformation_torch,

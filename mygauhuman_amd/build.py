@@ -22,6 +22,7 @@ SOURCES = [
     ("lbs.hip", []),
     ("attributes.hip", []),
     ("pose.hip", []),
+    ("sh_exchange.hip", []),
     ("loss.hip", []),
     ("gsr_api.hip", []),
 ]

@@ -133,4 +133,31 @@ __device__ __forceinline__ void sh_backward(int deg, const float3 pos, const flo
   dL_dmean[2] += (-d0x * d0z * dd0 - d0y * d0z * dd1 + (sum2 - d0z * d0z) * dd2) * inv32;
 }
 
+// the basis weights themselves: colour = sum_k w[k] * sh[k] (+0.5), i.e. dL_dsh[k] = w[k] * dL_dRGB (CR/backward.cu:40-116)
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float *w) {
+  w[0] = kSH0;
+  if (deg > 0) {
+    w[1] = -kSH1 * y;
+    w[2] = kSH1 * z;
+    w[3] = -kSH1 * x;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      w[4] = kSH2[0] * xy;
+      w[5] = kSH2[1] * yz;
+      w[6] = kSH2[2] * (2.f * zz - xx - yy);
+      w[7] = kSH2[3] * xz;
+      w[8] = kSH2[4] * (xx - yy);
+      if (deg > 2) {
+        w[9] = kSH3[0] * y * (3.f * xx - yy);
+        w[10] = kSH3[1] * xy * z;
+        w[11] = kSH3[2] * y * (4.f * zz - xx - yy);
+        w[12] = kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+        w[13] = kSH3[4] * x * (4.f * zz - xx - yy);
+        w[14] = kSH3[5] * z * (xx - yy);
+        w[15] = kSH3[6] * x * (xx - 3.f * yy);
+      }
+    }
+  }
+}
+
 }  // namespace gsr
