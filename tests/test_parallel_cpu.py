@@ -37,6 +37,16 @@ def _worker(rank, world, port, q):
     rad = torch.arange(P, dtype=torch.int32) * (rank + 1)
     parallel.all_reduce_densify_stats(acc, den, rad)
     views = [parallel.view_for_step(s, rank, world) for s in range(3)]
+    # compact SH exchange: every rank ends up with every rank's (masked dL_dRGB | campos) block, in rank order
+    ex = parallel.CompactShExchange(P, M, "cpu")
+    ex.mine[:P * 3].copy_(torch.arange(P * 3, dtype=torch.float32) + 1000.0 * rank)
+    ex.mine[P * 3:P * 3 + 3].copy_(torch.tensor([rank + 0.25, rank + 0.5, rank + 0.75]))
+    ex.exchange()
+    assert ex.world == world and ex.gathered.shape == (world, ex.stride) and ex.stride % 64 == 0
+    for r2 in range(world):
+        assert torch.equal(ex.gathered[r2, :P * 3], torch.arange(P * 3, dtype=torch.float32) + 1000.0 * r2)
+        assert torch.equal(ex.gathered[r2, P * 3:P * 3 + 3], torch.tensor([r2 + 0.25, r2 + 0.5, r2 + 0.75]))
+    assert parallel.gaussian_gradient_shapes(P, M, "sh_compact").keys() == {"means3D", "opacity", "scales", "rotations"}
     q.put((rank, {k: v.numpy() for k, v in mine.items()}, {k: v.clone().numpy() for k, v in b.views.items()},
            acc.numpy(), den.numpy(), rad.numpy(), views))
     dist.barrier()
