@@ -239,6 +239,19 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
                      float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
                      float *dL_doff_pose, gsr_stream_t stream);
 
+/* k-NN service replacing the un-vendored KNN_CUDA dependency (scene/gaussian_model.py:87-89).
+ * Semantics assumed for KNN_CUDA 0.2 (parity unpinned): exact brute-force k-NN, Euclidean distances in ascending order;
+ * here ties resolve to the lowest index.
+ *   gsr_knn_self: the k <= 3 nearest of every point among the SAME P points, the point itself included (what
+ *     knn(xyz, xyz) returns; :176,573,621,671): idx[P][k] int32, dist[P][k].  Workspace: gsr_dist2_workspace_bytes(P).
+ *   gsr_knn_nearest: nearest of N reference points for each of M queries (:727, distance of the Gaussians to the SMPL
+ *     vertices; :775 is fused into gsr_lbs_forward_grid): idx[M] and/or dist[M] (either may be null).
+ *     Workspace: gsr_lbs_workspace_bytes(N), 16-byte aligned. */
+int gsr_knn_self(int P, const float *points, int k, int *idx, float *dist, char *workspace, size_t workspace_bytes,
+                 gsr_stream_t stream);
+int gsr_knn_nearest(int M, const float *query, int N, const float *ref, int *idx, float *dist, char *workspace,
+                    size_t workspace_bytes, gsr_stream_t stream);
+
 /* Compact exchange of the SH-coefficient gradient between view-parallel ranks (extension).  For one view
  * dL_dsh[i][k][c] = w_k(dir_i) * dL_dRGB[i][c] (dir = normalise(mean - campos); dL_dRGB zeroed on clamped channels,
  * CR/backward.cu:40-116): ranks all-gather 12 B per Gaussian instead of all-reducing 12 M B.

@@ -17,8 +17,10 @@ __version__ = "0.1.0"
 
 
 def install_dropin():
-    """Make `import diff_gaussian_rasterization`, `from simple_knn._C import distCUDA2` resolve to this package."""
+    """Make `import diff_gaussian_rasterization`, `from simple_knn._C import distCUDA2`, `from knn_cuda import KNN` resolve
+    to this package."""
     for theirs, ours in (("diff_gaussian_rasterization", "mygauhuman_amd.diff_gaussian_rasterization"),
                          ("simple_knn", "mygauhuman_amd.simple_knn"),
-                         ("simple_knn._C", "mygauhuman_amd.simple_knn._C")):
+                         ("simple_knn._C", "mygauhuman_amd.simple_knn._C"),
+                         ("knn_cuda", "mygauhuman_amd.knn_cuda")):
         sys.modules[theirs] = importlib.import_module(ours)

@@ -220,6 +220,95 @@ __global__ __launch_bounds__(KNN_Q) void box_mean_dist_kernel(int P, const float
   if (live) dists[idx_s[idx]] = (b0 + b1 + b2) / 3.0f;
 }
 
+// ---- k nearest neighbours WITH indices (k <= 3), the point itself included: what KNN_CUDA returns for ref == query
+// (scene/gaussian_model.py:176,573,621,671).  Same box traversal; candidates are ranked by (squared distance, original
+// index) lexicographically, so equal distances resolve to the lowest index whatever the traversal order.
+__device__ __forceinline__ bool pair_less(float da, uint32_t ia, float db, uint32_t ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ void kbest3_idx(float d, uint32_t id, float (&bd)[3], uint32_t (&bi)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (pair_less(d, id, bd[k], bi[k])) {
+      const float td = bd[k];
+      const uint32_t ti = bi[k];
+      bd[k] = d;
+      bi[k] = id;
+      d = td;
+      id = ti;
+    }
+  }
+}
+
+__global__ __launch_bounds__(KNN_Q) void box_knn_kernel(int P, int K, const float *sorted, const uint32_t *idx_s, const float *boxes,
+                                                        int nb, int *out_idx, float *out_dist) {
+  __shared__ float sx[KNN_BOX], sy[KNN_BOX], sz[KNN_BOX];
+  __shared__ uint32_t sid[KNN_BOX];
+  const int idx = blockIdx.x * KNN_Q + threadIdx.x;
+  const bool live = idx < P;
+  float px = 0, py = 0, pz = 0;
+  float r0 = FLT_MAX, r1 = FLT_MAX, r2 = FLT_MAX;
+  if (live) {
+    px = sorted[3 * (size_t)idx];
+    py = sorted[3 * (size_t)idx + 1];
+    pz = sorted[3 * (size_t)idx + 2];
+    for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
+      if (i == idx) continue;
+      kbest3(sqdist3(px, py, pz, sorted[3 * (size_t)i], sorted[3 * (size_t)i + 1], sorted[3 * (size_t)i + 2]), r0, r1, r2);
+    }
+  }
+  const float reject = r2;  // an upper bound of the 3rd-nearest distance (self excluded, so even looser than needed)
+  float bd[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  uint32_t bi[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  for (int b = 0; b < nb; b++) {
+    bool want = false;
+    if (live) {
+      const float *bx = boxes + 6 * b;
+      float dfx = 0, dfy = 0, dfz = 0;
+      if (px < bx[0] || px > bx[3]) dfx = fminf(fabsf(px - bx[0]), fabsf(px - bx[3]));
+      if (py < bx[1] || py > bx[4]) dfy = fminf(fabsf(py - bx[1]), fabsf(py - bx[4]));
+      if (pz < bx[2] || pz > bx[5]) dfz = fminf(fabsf(pz - bx[2]), fabsf(pz - bx[5]));
+      const float dist = dfx * dfx + dfy * dfy + dfz * dfz;
+      want = !(dist > reject || dist > bd[2]);  // boxes at exactly the bound are still visited (index tie-break)
+    }
+    if (!__syncthreads_or(want ? 1 : 0)) continue;
+    const int lo = b * KNN_BOX, cnt = min(P - lo, KNN_BOX);
+    for (int i = threadIdx.x; i < cnt; i += KNN_Q) {
+      sx[i] = sorted[3 * (size_t)(lo + i)];
+      sy[i] = sorted[3 * (size_t)(lo + i) + 1];
+      sz[i] = sorted[3 * (size_t)(lo + i) + 2];
+      sid[i] = idx_s[lo + i];
+    }
+    __syncthreads();
+    if (want)
+      for (int i = 0; i < cnt; i++) kbest3_idx(sqdist3(px, py, pz, sx[i], sy[i], sz[i]), sid[i], bd, bi);
+  }
+  if (live) {
+    const size_t o = (size_t)idx_s[idx] * K;
+    for (int k = 0; k < K; k++) {
+      out_idx[o + k] = (int)bi[k];
+      out_dist[o + k] = sqrtf(bd[k]);
+    }
+  }
+}
+
+int knn_self(int P, int K, const float *points, int *out_idx, float *out_dist, char *workspace, hipStream_t stream) {
+  if (P <= 0) return GSR_OK;
+  KnnWorkspace w = knn_carve(workspace, (size_t)P);
+  const int nred = knn_red_blocks(P);
+  hipLaunchKernelGGL(aabb_partial_kernel, dim3(nred), dim3(256), 0, stream, P, points, w.partial);
+  hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(64), 0, stream, nred, w.partial, w.minmax);
+  hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, w.minmax, w.codes, w.idx);
+  GSR_LAUNCH_CHECK(stream, 0);
+  int rc = radix_sort_u32((size_t)P, w.codes, w.idx, w.tk, w.tv, w.codes_s, w.idx_s, 32, w.hist, stream, 0);
+  if (rc != GSR_OK) return rc;
+  const int nb = (P + KNN_BOX - 1) / KNN_BOX;
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, w.idx_s, w.sorted);
+  hipLaunchKernelGGL(box_minmax_kernel, dim3(nb), dim3(256), 0, stream, P, w.sorted, w.boxes);
+  hipLaunchKernelGGL(box_knn_kernel, dim3((P + KNN_Q - 1) / KNN_Q), dim3(KNN_Q), 0, stream, P, K, w.sorted, w.idx_s, w.boxes, nb,
+                     out_idx, out_dist);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
 int knn_dist2(int P, const float *points, float *mean_dists, char *workspace, hipStream_t stream) {
   if (P <= 0) return GSR_OK;
   KnnWorkspace w = knn_carve(workspace, (size_t)P);
@@ -255,5 +344,18 @@ int gsr_dist2(int P, const float *points, float *mean_dists, char *workspace, si
     return GSR_ENOMEM;
   }
   return gsr::knn_dist2(P, points, mean_dists, workspace, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gsr_knn_self(int P, const float *points, int k, int *idx, float *dist, char *workspace, size_t workspace_bytes,
+                 gsr_stream_t stream) {
+  if (P < 0 || k < 1 || k > 3 || (P > 0 && (!points || !idx || !dist))) {
+    gsr::set_error("gsr_knn_self: bad arguments (k must be 1..3)");
+    return GSR_EINVAL;
+  }
+  if (P > 0 && (!workspace || workspace_bytes < gsr_dist2_workspace_bytes(P))) {
+    gsr::set_error("gsr_knn_self: workspace too small (%zu < %zu)", workspace_bytes, gsr_dist2_workspace_bytes(P));
+    return GSR_ENOMEM;
+  }
+  return gsr::knn_self(P, k, points, idx, dist, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 }

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void lbs_grid_build_kernel(int V, const
 // exact nearest vertex of q through the grid: rings of cells of growing Chebyshev radius around q's cell; after ring r every
 // unvisited vertex is farther than r*h (r whole cells lie in between), so the search stops once best < that bound.
 // (distance, index) is compared lexicographically: the lowest index wins ties, like the brute-force scan.
-__device__ __forceinline__ int grid_nearest(const char *ws, const float *q) {
+__device__ __forceinline__ int grid_nearest(const char *ws, const float *q, float *best_d2 = nullptr) {
   const GridHeader *g = reinterpret_cast<const GridHeader *>(ws);
   const uint32_t *cells = reinterpret_cast<const uint32_t *>(ws + grid_cells_offset());
   const float4 *sorted = reinterpret_cast<const float4 *>(ws + grid_sorted_offset());
@@ -198,7 +198,20 @@ __device__ __forceinline__ int grid_nearest(const char *ws, const float *q) {
         }
       }
   }
+  if (best_d2) *best_d2 = best;
   return bid;
+}
+
+// stand-alone nearest-reference-point query through the grid (the k = 1, ref != query use of KNN_CUDA,
+// scene/gaussian_model.py:727: distance of every Gaussian to the SMPL surface)
+__global__ __launch_bounds__(256) void grid_nearest_kernel(int M, const float *query, const char *ws, int *idx, float *dist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const float q[3] = {query[3 * (size_t)i], query[3 * (size_t)i + 1], query[3 * (size_t)i + 2]};
+  float d2;
+  const int id = grid_nearest(ws, q, &d2);
+  if (idx) idx[i] = id;
+  if (dist) dist[i] = sqrtf(d2);
 }
 
 struct LbsArgs {
@@ -551,6 +564,25 @@ int gsr_lbs_forward(int P, int V, const float *query, const float *normals, cons
 }
 
 size_t gsr_lbs_workspace_bytes(int V) { return V > 0 ? gsr::grid_workspace_bytes(V) : 0; }
+
+int gsr_knn_nearest(int M, const float *query, int N, const float *ref, int *idx, float *dist, char *workspace,
+                    size_t workspace_bytes, gsr_stream_t stream_) {
+  if (M < 0 || N <= 0 || !ref || (M > 0 && (!query || (!idx && !dist)))) {
+    gsr::set_error("gsr_knn_nearest: bad arguments");
+    return GSR_EINVAL;
+  }
+  if (M == 0) return GSR_OK;
+  if (!workspace || workspace_bytes < gsr::grid_workspace_bytes(N) || reinterpret_cast<size_t>(workspace) % 16 != 0) {
+    gsr::set_error("gsr_knn_nearest: workspace of %zu bytes (16-byte aligned) required, got %zu", gsr::grid_workspace_bytes(N),
+                   workspace_bytes);
+    return GSR_EINVAL;
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(gsr::lbs_grid_build_kernel, dim3(1), dim3(gsr::GRID_BLOCK), 0, stream, N, ref, workspace);
+  hipLaunchKernelGGL(gsr::grid_nearest_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, M, query, workspace, idx, dist);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
 
 int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals, const float *smpl_verts, const float *weights,
                          const float *lbs_offsets, const float *A_big, const float *A_pose, const float *off_big,

@@ -186,6 +186,23 @@ def dist2_morton(points):
     return out, codes, order
 
 
+def knn_self(points, k):
+    """(idx [P,k] int32, dist [P,k]) of the k <= 3 nearest among the same points, self included, brute force."""
+    points = _c(points, f32)
+    P = points.shape[0]
+    idx, dist = np.zeros((P, k), np.int32), np.zeros((P, k), f32)
+    lib().oracle_knn_self(C.c_int(P), _p(points, _fp), C.c_int(k), _p(idx, _ip), _p(dist, _fp))
+    return idx, dist
+
+
+def nearest_dist(query, verts, idx):
+    query, verts, idx = _c(query, f32), _c(verts, f32), np.ascontiguousarray(idx, np.int32)
+    out = np.zeros(query.shape[0], f32)
+    lib().oracle_nearest_dist(C.c_int(query.shape[0]), _p(query, _fp), C.c_int(verts.shape[0]), _p(verts, _fp), _p(idx, _ip),
+                              _p(out, _fp))
+    return out
+
+
 def nearest_vertex(query, verts):
     query, verts = _c(query, f32), _c(verts, f32)
     out = np.zeros(query.shape[0], np.int32)

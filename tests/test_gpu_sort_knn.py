@@ -77,3 +77,52 @@ def test_dist2_clustered_and_shifted(oracle):
     pts[:, 2] = 7.0
     got = distCUDA2(util.to_dev(pts)).cpu().numpy()
     np.testing.assert_array_equal(got, oracle.dist2_brute(pts))
+
+
+@pytest.mark.parametrize("P,k,kind", [(1, 1, "normal"), (2, 2, "normal"), (3, 3, "normal"), (5000, 2, "normal"), (5000, 3, "clustered"),
+                                      (20000, 3, "surface"), (4000, 3, "duplicates"), (3000, 2, "grid")])
+def test_knn_self_matches_brute_force(oracle, P, k, kind):
+    """gsr_knn_self against the brute-force oracle: indices bit-exact (lowest index on ties), distances to 1 ulp."""
+    from mygauhuman_amd import knn_cuda
+    rng = np.random.default_rng(P + k)
+    pts = rng.normal(0, 1, (P, 3)).astype(np.float32)
+    if kind == "clustered":
+        pts = (pts * 0.01 + rng.integers(0, 5, (P, 1)) * 3.0).astype(np.float32)
+    elif kind == "surface":
+        pts[:, 2] = (0.1 * np.sin(3 * pts[:, 0])).astype(np.float32)
+    elif kind == "duplicates":
+        pts = np.concatenate([pts[:P // 2], pts[:P // 2]]).astype(np.float32)
+    elif kind == "grid":   # many exactly equal distances
+        pts = np.stack(np.meshgrid(np.arange(15), np.arange(20), np.arange(10), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    kk = min(k, pts.shape[0])
+    want_i, want_d = oracle.knn_self(pts, kk)
+    d, i = knn_cuda.knn_self(torch.from_numpy(pts).cuda(), kk)
+    np.testing.assert_array_equal(i.cpu().numpy(), want_i)
+    np.testing.assert_allclose(d.cpu().numpy(), want_d, rtol=2e-7, atol=0)
+
+
+def test_knn_module_surface(oracle):
+    """The KNN_CUDA call surface: (dist [B,M,k], idx [B,M,k] int64), transpose_mode True and False, self and ref != query."""
+    from mygauhuman_amd import knn_cuda
+    rng = np.random.default_rng(4)
+    xyz = torch.from_numpy(rng.normal(0, 0.5, (3000, 3)).astype(np.float32)).cuda()
+    verts = torch.from_numpy(rng.normal(0, 0.5, (700, 3)).astype(np.float32)).cuda()
+    d3, i3 = knn_cuda.KNN(k=3, transpose_mode=True)(xyz[None], xyz[None])
+    assert d3.shape == (1, 3000, 3) and i3.shape == (1, 3000, 3) and i3.dtype == torch.int64
+    wi, wd = oracle.knn_self(xyz.cpu().numpy(), 3)
+    np.testing.assert_array_equal(i3[0].cpu().numpy(), wi)
+    assert torch.equal(i3[0, :, 0].cpu(), torch.arange(3000))  # the point itself comes first
+    d1, i1 = knn_cuda.KNN(k=1, transpose_mode=True)(verts[None], xyz[None])      # gaussian_model.py:727
+    ids = oracle.nearest_vertex(xyz.cpu().numpy(), verts.cpu().numpy())
+    np.testing.assert_array_equal(i1[0, :, 0].cpu().numpy(), ids)
+    np.testing.assert_allclose(d1[0, :, 0].cpu().numpy(), oracle.nearest_dist(xyz.cpu().numpy(), verts.cpu().numpy(), ids), rtol=2e-7)
+    xt = xyz.t()[None].contiguous()
+    dT, iT = knn_cuda.KNN(k=2)(xt, xt)  # default layout [B, 3, N]
+    assert dT.shape == (1, 2, 3000) and torch.equal(iT[0].t().cpu(), i3[0, :, :2].cpu())
+    with pytest.raises(NotImplementedError):
+        knn_cuda.KNN(k=2, transpose_mode=True)(verts[None], xyz[None])
+    with pytest.raises(RuntimeError):
+        knn_cuda.knn_self(xyz.cpu(), 2)
+    import mygauhuman_amd
+    mygauhuman_amd.install_dropin()
+    from knn_cuda import KNN  # noqa: F401  (the reference's import, scene/gaussian_model.py:23)
