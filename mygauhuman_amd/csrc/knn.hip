@@ -1,53 +1,59 @@
-// knn.hip -- distCUDA2: mean squared distance to the 3 nearest neighbours (replaces SimpleKNN::knn,
-// SK/simple_knn.cu:185-221).  Built with -ffp-contract=off so squared distances carry the same roundings as the
-// oracle; the search is exact, so the result does not depend on the traversal order.
+// knn.hip -- exact k-nearest-neighbour kernels:
+//   distCUDA2  mean squared distance to the 3 nearest OTHER points (replaces SimpleKNN::knn, SK/simple_knn.cu:185-221)
+//   knn_self   the k <= 3 nearest of every point among the same points, with indices (KNN_CUDA's knn(xyz, xyz),
+//              scene/gaussian_model.py:176,573,621,671)
+// Built with -ffp-contract=off so squared distances carry the same roundings as the oracle; the search is exact, so results
+// do not depend on the traversal order (ties between equal distances resolve to the lowest index).
 //
-// Same geometric structure as the reference (AABB incl. the origin -> 30-bit Morton codes -> sort -> boxes of 1024
-// Morton-consecutive points -> pruned exact search), re-shaped for MI355X:
-//   * no host round trips: the AABB stays on the device (the reference syncs twice, SK/simple_knn.cu:197,200);
-//   * no per-call allocations: one caller-provided workspace (the reference makes 7 device allocations);
-//   * points are gathered into Morton order once, so a candidate box is a contiguous 12 KB run that a workgroup
-//     stages into LDS with coalesced loads and every lane then reads by broadcast (the reference gathers
-//     points[indices[i]] from global memory inside the innermost loop, SK/simple_knn.cu:175-180);
-//   * a workgroup owns 256 Morton-consecutive query points and a box is staged when ANY of them still needs it
-//     (__syncthreads_or), each lane keeps the reference's own reject/best[2] test.
+// The reference sorts 30-bit Morton codes and scans boxes of 1024 Morton-consecutive points with AABB pruning
+// (SK/simple_knn.cu:78-183): every query visits tens of boxes x 1024 candidates.  Here the points are binned into an
+// ISOTROPIC uniform grid over their bounding cube (2^L cells per axis, about two points per cell for volumetric data:
+// L = ceil(log2(cbrt(P/2)))) with one short radix sort of the linear cell ids; a boundary pass turns the sorted ids
+// into a (start, end) table without any scan; a query then walks rings of cells of growing Chebyshev radius around
+// its own cell and stops as soon as its k-th best distance is below (r-1) h, the distance every unvisited point exceeds.
+// 200k surface points: ~100 candidates per query instead of ~20k.  No host round trips, one caller-provided workspace.
 #include <float.h>
 
 #include "gsr_common.h"
 
 namespace gsr {
 
-constexpr int KNN_BOX = 1024;  // SK/simple_knn.cu:12 BOX_SIZE
-constexpr int KNN_Q = 256;     // query points per workgroup
-
-struct KnnWorkspace {
-  float *partial;    // [nred][6]
-  float *minmax;     // [6]
-  uint32_t *codes, *idx, *codes_s, *idx_s, *tk, *tv, *hist;
-  float *sorted;     // [P][3] points in Morton order
-  float *boxes;      // [nb][6]
+struct KnnHeader {
+  float mn[3], h, inv_h;
 };
+struct KnnWorkspace {
+  float *partial;    // [1024][6]
+  KnnHeader *hdr;
+  uint32_t *keys, *idx, *keys_s, *idx_s, *tk, *tv, *hist;
+  float4 *sorted;    // [P] points in cell order: x, y, z, original index bits
+  uint2 *table;      // [res^3] (start, end) of each cell in `sorted`; (0, 0) for empty cells
+};
+static inline int knn_level(size_t P) {
+  int L = 2;
+  while (L < 8 && (double)(1u << (3 * L)) * 2.0 < (double)P) L++;
+  return L;
+}
 static inline int knn_red_blocks(int P) { return min(1024, (P + 1023) / 1024); }
 static KnnWorkspace knn_carve(char *p, size_t P) {
   KnnWorkspace w;
   size_t n = P ? P : 1;
   carve(p, w.partial, (size_t)1024 * 6);
-  carve(p, w.minmax, 8);
-  carve(p, w.codes, n);
+  carve(p, w.hdr, 1);
+  carve(p, w.keys, n);
   carve(p, w.idx, n);
-  carve(p, w.codes_s, n);
+  carve(p, w.keys_s, n);
   carve(p, w.idx_s, n);
   carve(p, w.tk, n);
   carve(p, w.tv, n);
   carve(p, w.hist, sort_hist_words(n));
-  carve(p, w.sorted, n * 3);
-  carve(p, w.boxes, ((n + KNN_BOX - 1) / KNN_BOX) * 6);
+  carve(p, w.sorted, n);
+  carve(p, w.table, (size_t)1 << (3 * knn_level(n)));
   return w;
 }
 size_t knn_workspace_bytes(size_t P) {
   KnnWorkspace w = knn_carve(nullptr, P);
   size_t n = P ? P : 1;
-  return reinterpret_cast<size_t>(w.boxes + ((n + KNN_BOX - 1) / KNN_BOX) * 6) + 512;
+  return reinterpret_cast<size_t>(w.table + ((size_t)1 << (3 * knn_level(n)))) + 512;
 }
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -61,10 +67,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// AABB of the points and the origin (init = (0,0,0), SK/simple_knn.cu:191-200), two levels
+// bounding box of the points, two levels
 __global__ __launch_bounds__(256) void aabb_partial_kernel(int P, const float *pts, float *partial) {
   __shared__ float s[4][6];
-  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -89,140 +95,59 @@ __global__ __launch_bounds__(256) void aabb_partial_kernel(int P, const float *p
     partial[blockIdx.x * 6 + threadIdx.x] = v;
   }
 }
-__global__ void aabb_final_kernel(int nred, const float *partial, float *minmax) {
-  const int k = threadIdx.x;
-  if (k >= 6) return;
-  float v = 0.f;
-  for (int b = 0; b < nred; b++) v = k < 3 ? fminf(v, partial[b * 6 + k]) : fmaxf(v, partial[b * 6 + k]);
-  minmax[k] = v;
+__global__ void aabb_final_kernel(int nred, const float *partial, KnnHeader *hdr, int res) {
+  if (threadIdx.x != 0) return;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int b = 0; b < nred; b++)
+    for (int k = 0; k < 3; k++) {
+      mn[k] = fminf(mn[k], partial[b * 6 + k]);
+      mx[k] = fmaxf(mx[k], partial[b * 6 + 3 + k]);
+    }
+  float ext = 0.f;
+  for (int k = 0; k < 3; k++) {
+    hdr->mn[k] = mn[k];
+    ext = fmaxf(ext, mx[k] - mn[k]);
+  }
+  const float h = fmaxf(ext / (float)res, 1e-30f);
+  hdr->h = h;
+  hdr->inv_h = 1.0f / h;
 }
 
-__device__ __forceinline__ uint32_t prep_morton(uint32_t x) {  // SK/simple_knn.cu:45-52
-  x = (x | (x << 16)) & 0x030000FF;
-  x = (x | (x << 8)) & 0x0300F00F;
-  x = (x | (x << 4)) & 0x030C30C3;
-  x = (x | (x << 2)) & 0x09249249;
-  return x;
+__device__ __forceinline__ int cell_coord(float x, float lo, float inv_h, int res) {
+  const int c = (int)floorf((x - lo) * inv_h);
+  return min(max(c, 0), res - 1);
 }
-__device__ __forceinline__ uint32_t f2u_sat(float f) {  // cvt.rzi.u32.f32: truncate, saturate, NaN -> 0
-  if (!(f > 0.f)) return 0u;
-  if (f >= 4294967296.0f) return 0xFFFFFFFFu;
-  return (uint32_t)f;
-}
-__global__ void morton_kernel(int P, const float *pts, const float *minmax, uint32_t *codes, uint32_t *idx) {
+
+__global__ void cell_key_kernel(int P, const float *pts, const KnnHeader *hdr, int res, uint32_t *keys, uint32_t *idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
-  uint32_t c[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const float mn = minmax[k], mx = minmax[3 + k];
-    c[k] = prep_morton(f2u_sat(((pts[3 * (size_t)i + k] - mn) / (mx - mn)) * (float)((1 << 10) - 1)));
-  }
-  codes[i] = c[0] | (c[1] << 1) | (c[2] << 2);
+  const int cx = cell_coord(pts[3 * (size_t)i], hdr->mn[0], hdr->inv_h, res);
+  const int cy = cell_coord(pts[3 * (size_t)i + 1], hdr->mn[1], hdr->inv_h, res);
+  const int cz = cell_coord(pts[3 * (size_t)i + 2], hdr->mn[2], hdr->inv_h, res);
+  keys[i] = (uint32_t)((cz * res + cy) * res + cx);
   idx[i] = (uint32_t)i;
 }
 
-__global__ void gather_sorted_kernel(int P, const float *pts, const uint32_t *idx_s, float *sorted) {
+// points into cell order + the (start, end) table from the boundaries of the sorted ids (the table was zeroed)
+__global__ void gather_table_kernel(int P, const float *pts, const uint32_t *keys_s, const uint32_t *idx_s, float4 *sorted,
+                                    uint2 *table) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
-  const uint32_t g = idx_s[i];
-  sorted[3 * (size_t)i + 0] = pts[3 * (size_t)g + 0];
-  sorted[3 * (size_t)i + 1] = pts[3 * (size_t)g + 1];
-  sorted[3 * (size_t)i + 2] = pts[3 * (size_t)g + 2];
+  const uint32_t g = idx_s[i], c = keys_s[i];
+  sorted[i] = make_float4(pts[3 * (size_t)g], pts[3 * (size_t)g + 1], pts[3 * (size_t)g + 2], __uint_as_float(g));
+  if (i == 0 || keys_s[i - 1] != c) table[c].x = (uint32_t)i;
+  if (i == P - 1 || keys_s[i + 1] != c) table[c].y = (uint32_t)(i + 1);
 }
 
-// AABB of each run of 1024 Morton-consecutive points (SK/simple_knn.cu:78-117)
-__global__ __launch_bounds__(256) void box_minmax_kernel(int P, const float *sorted, float *boxes) {
-  __shared__ float s[4][6];
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  const int lo = blockIdx.x * KNN_BOX, hi = min(P, lo + KNN_BOX);
-  for (int i = lo + threadIdx.x; i < hi; i += 256)
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const float v = sorted[3 * (size_t)i + k];
-      mn[k] = fminf(mn[k], v);
-      mx[k] = fmaxf(mx[k], v);
-    }
-  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    mn[k] = wave_min(mn[k]);
-    mx[k] = wave_max(mx[k]);
-    if (lane == 0) {
-      s[wave][k] = mn[k];
-      s[wave][3 + k] = mx[k];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    float v = s[0][threadIdx.x];
-    for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-    boxes[blockIdx.x * 6 + threadIdx.x] = v;
-  }
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = bx - ax, dy = by - ay, dz = bz - az;
+  return dx * dx + dy * dy + dz * dz;
 }
-
 __device__ __forceinline__ void kbest3(float d, float &b0, float &b1, float &b2) {  // SK/simple_knn.cu:131-145
   if (b0 > d) { const float t = b0; b0 = d; d = t; }
   if (b1 > d) { const float t = b1; b1 = d; d = t; }
   if (b2 > d) { b2 = d; }
 }
-__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
-  const float dx = bx - ax, dy = by - ay, dz = bz - az;
-  return dx * dx + dy * dy + dz * dz;
-}
-
-// SK/simple_knn.cu:147-183
-__global__ __launch_bounds__(KNN_Q) void box_mean_dist_kernel(int P, const float *sorted, const uint32_t *idx_s,
-                                                              const float *boxes, int nb, float *dists) {
-  __shared__ float sx[KNN_BOX], sy[KNN_BOX], sz[KNN_BOX];
-  const int idx = blockIdx.x * KNN_Q + threadIdx.x;
-  const bool live = idx < P;
-  float px = 0, py = 0, pz = 0;
-  float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
-  if (live) {
-    px = sorted[3 * (size_t)idx];
-    py = sorted[3 * (size_t)idx + 1];
-    pz = sorted[3 * (size_t)idx + 2];
-    for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
-      if (i == idx) continue;
-      kbest3(sqdist3(px, py, pz, sorted[3 * (size_t)i], sorted[3 * (size_t)i + 1], sorted[3 * (size_t)i + 2]), b0, b1, b2);
-    }
-  }
-  const float reject = b2;
-  b0 = b1 = b2 = FLT_MAX;
-  for (int b = 0; b < nb; b++) {
-    bool want = false;
-    if (live) {
-      const float *bx = boxes + 6 * b;
-      float dfx = 0, dfy = 0, dfz = 0;
-      if (px < bx[0] || px > bx[3]) dfx = fminf(fabsf(px - bx[0]), fabsf(px - bx[3]));
-      if (py < bx[1] || py > bx[4]) dfy = fminf(fabsf(py - bx[1]), fabsf(py - bx[4]));
-      if (pz < bx[2] || pz > bx[5]) dfz = fminf(fabsf(pz - bx[2]), fabsf(pz - bx[5]));
-      const float dist = dfx * dfx + dfy * dfy + dfz * dfz;
-      want = !(dist > reject || dist > b2);
-    }
-    if (!__syncthreads_or(want ? 1 : 0)) continue;  // also fences the previous iteration's LDS reads
-    const int lo = b * KNN_BOX, cnt = min(P - lo, KNN_BOX);
-    for (int i = threadIdx.x; i < cnt; i += KNN_Q) {
-      sx[i] = sorted[3 * (size_t)(lo + i)];
-      sy[i] = sorted[3 * (size_t)(lo + i) + 1];
-      sz[i] = sorted[3 * (size_t)(lo + i) + 2];
-    }
-    __syncthreads();
-    if (want) {
-      const int self = idx - lo;  // position of this point inside the box, if it is in it
-      for (int i = 0; i < cnt; i++) {
-        if (i == self) continue;
-        kbest3(sqdist3(px, py, pz, sx[i], sy[i], sz[i]), b0, b1, b2);
-      }
-    }
-  }
-  if (live) dists[idx_s[idx]] = (b0 + b1 + b2) / 3.0f;
-}
-
-// ---- k nearest neighbours WITH indices (k <= 3), the point itself included: what KNN_CUDA returns for ref == query
-// (scene/gaussian_model.py:176,573,621,671).  Same box traversal; candidates are ranked by (squared distance, original
-// index) lexicographically, so equal distances resolve to the lowest index whatever the traversal order.
 __device__ __forceinline__ bool pair_less(float da, uint32_t ia, float db, uint32_t ib) { return da < db || (da == db && ia < ib); }
 __device__ __forceinline__ void kbest3_idx(float d, uint32_t id, float (&bd)[3], uint32_t (&bi)[3]) {
 #pragma unroll
@@ -238,73 +163,73 @@ __device__ __forceinline__ void kbest3_idx(float d, uint32_t id, float (&bd)[3],
   }
 }
 
-__global__ __launch_bounds__(KNN_Q) void box_knn_kernel(int P, int K, const float *sorted, const uint32_t *idx_s, const float *boxes,
-                                                        int nb, int *out_idx, float *out_dist) {
-  __shared__ float sx[KNN_BOX], sy[KNN_BOX], sz[KNN_BOX];
-  __shared__ uint32_t sid[KNN_BOX];
-  const int idx = blockIdx.x * KNN_Q + threadIdx.x;
-  const bool live = idx < P;
-  float px = 0, py = 0, pz = 0;
-  float r0 = FLT_MAX, r1 = FLT_MAX, r2 = FLT_MAX;
-  if (live) {
-    px = sorted[3 * (size_t)idx];
-    py = sorted[3 * (size_t)idx + 1];
-    pz = sorted[3 * (size_t)idx + 2];
-    for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
-      if (i == idx) continue;
-      kbest3(sqdist3(px, py, pz, sorted[3 * (size_t)i], sorted[3 * (size_t)i + 1], sorted[3 * (size_t)i + 2]), r0, r1, r2);
-    }
-  }
-  const float reject = r2;  // an upper bound of the 3rd-nearest distance (self excluded, so even looser than needed)
+// One thread per point, in cell order (neighbouring threads walk the same cells).  WITH_IDX = false: distCUDA2 (the point
+// itself is skipped BY POSITION, coincident other points count, like SK/simple_knn.cu:170); true: knn_self (self included).
+template <bool WITH_IDX>
+__global__ __launch_bounds__(256) void grid_knn_kernel(int P, int K, const KnnHeader *hdr, int res, const float4 *sorted,
+                                                       const uint2 *table, float *mean_dists, int *out_idx, float *out_dist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float4 p = sorted[i];
+  const float h = hdr->h;
+  const int cx = cell_coord(p.x, hdr->mn[0], hdr->inv_h, res);
+  const int cy = cell_coord(p.y, hdr->mn[1], hdr->inv_h, res);
+  const int cz = cell_coord(p.z, hdr->mn[2], hdr->inv_h, res);
   float bd[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
   uint32_t bi[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-  for (int b = 0; b < nb; b++) {
-    bool want = false;
-    if (live) {
-      const float *bx = boxes + 6 * b;
-      float dfx = 0, dfy = 0, dfz = 0;
-      if (px < bx[0] || px > bx[3]) dfx = fminf(fabsf(px - bx[0]), fabsf(px - bx[3]));
-      if (py < bx[1] || py > bx[4]) dfy = fminf(fabsf(py - bx[1]), fabsf(py - bx[4]));
-      if (pz < bx[2] || pz > bx[5]) dfz = fminf(fabsf(pz - bx[2]), fabsf(pz - bx[5]));
-      const float dist = dfx * dfx + dfy * dfy + dfz * dfz;
-      want = !(dist > reject || dist > bd[2]);  // boxes at exactly the bound are still visited (index tie-break)
+  const int rmax = max(max(max(cx, res - 1 - cx), max(cy, res - 1 - cy)), max(cz, res - 1 - cz));
+  for (int r = 0; r <= rmax; r++) {
+    if (r >= 2) {
+      // every point not visited yet sits at least r cells away along some axis: farther than (r - 1) h
+      const float lb = (float)(r - 1) * h * 0.9999f;
+      if (bd[2] < lb * lb) break;
     }
-    if (!__syncthreads_or(want ? 1 : 0)) continue;
-    const int lo = b * KNN_BOX, cnt = min(P - lo, KNN_BOX);
-    for (int i = threadIdx.x; i < cnt; i += KNN_Q) {
-      sx[i] = sorted[3 * (size_t)(lo + i)];
-      sy[i] = sorted[3 * (size_t)(lo + i) + 1];
-      sz[i] = sorted[3 * (size_t)(lo + i) + 2];
-      sid[i] = idx_s[lo + i];
-    }
-    __syncthreads();
-    if (want)
-      for (int i = 0; i < cnt; i++) kbest3_idx(sqdist3(px, py, pz, sx[i], sy[i], sz[i]), sid[i], bd, bi);
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, res - 1), y0 = max(cy - r, 0), y1 = min(cy + r, res - 1);
+    for (int z = z0; z <= z1; z++)
+      for (int y = y0; y <= y1; y++) {
+        const bool shell = (z - cz == r) || (cz - z == r) || (y - cy == r) || (cy - y == r);
+        const int xs = shell ? 1 : max(2 * r, 1);  // shell rows: every x; inner rows: only x = cx - r and cx + r
+        for (int x = cx - r; x <= cx + r; x += xs) {
+          if (x < 0 || x >= res) continue;
+          const uint2 se = table[((size_t)z * res + y) * res + x];
+          for (uint32_t j = se.x; j < se.y; j++) {
+            const float4 q = sorted[j];
+            const float d = sqdist3(p.x, p.y, p.z, q.x, q.y, q.z);
+            if (WITH_IDX) {
+              kbest3_idx(d, __float_as_uint(q.w), bd, bi);
+            } else if ((int)j != i) {
+              kbest3(d, bd[0], bd[1], bd[2]);
+            }
+          }
+        }
+      }
   }
-  if (live) {
-    const size_t o = (size_t)idx_s[idx] * K;
+  const uint32_t self = __float_as_uint(p.w);
+  if (WITH_IDX) {
     for (int k = 0; k < K; k++) {
-      out_idx[o + k] = (int)bi[k];
-      out_dist[o + k] = sqrtf(bd[k]);
+      out_idx[(size_t)self * K + k] = (int)bi[k];
+      out_dist[(size_t)self * K + k] = sqrtf(bd[k]);
     }
+  } else {
+    mean_dists[self] = (bd[0] + bd[1] + bd[2]) / 3.0f;
   }
 }
 
-int knn_self(int P, int K, const float *points, int *out_idx, float *out_dist, char *workspace, hipStream_t stream) {
-  if (P <= 0) return GSR_OK;
-  KnnWorkspace w = knn_carve(workspace, (size_t)P);
+static int knn_build(int P, const float *points, const KnnWorkspace &w, int L, hipStream_t stream) {
+  const int res = 1 << L;
   const int nred = knn_red_blocks(P);
   hipLaunchKernelGGL(aabb_partial_kernel, dim3(nred), dim3(256), 0, stream, P, points, w.partial);
-  hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(64), 0, stream, nred, w.partial, w.minmax);
-  hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, w.minmax, w.codes, w.idx);
+  hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(64), 0, stream, nred, w.partial, w.hdr, res);
+  hipLaunchKernelGGL(cell_key_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, w.hdr, res, w.keys, w.idx);
   GSR_LAUNCH_CHECK(stream, 0);
-  int rc = radix_sort_u32((size_t)P, w.codes, w.idx, w.tk, w.tv, w.codes_s, w.idx_s, 32, w.hist, stream, 0);
+  const int end_bit = 3 * L;
+  // pass 0 reads (keys, idx) and writes (tk, tv), then ping-pongs with (keys_s, idx_s)
+  int rc = radix_sort_u32((size_t)P, w.keys, w.idx, w.tk, w.tv, w.keys_s, w.idx_s, end_bit, w.hist, stream, 0);
   if (rc != GSR_OK) return rc;
-  const int nb = (P + KNN_BOX - 1) / KNN_BOX;
-  hipLaunchKernelGGL(gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, w.idx_s, w.sorted);
-  hipLaunchKernelGGL(box_minmax_kernel, dim3(nb), dim3(256), 0, stream, P, w.sorted, w.boxes);
-  hipLaunchKernelGGL(box_knn_kernel, dim3((P + KNN_Q - 1) / KNN_Q), dim3(KNN_Q), 0, stream, P, K, w.sorted, w.idx_s, w.boxes, nb,
-                     out_idx, out_dist);
+  const bool in_x = radix_passes(end_bit) % 2 == 1;
+  const uint32_t *ks = in_x ? w.tk : w.keys_s, *is = in_x ? w.tv : w.idx_s;
+  GSR_HIP(hipMemsetAsync(w.table, 0, sizeof(uint2) * ((size_t)1 << (3 * L)), stream));
+  hipLaunchKernelGGL(gather_table_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, ks, is, w.sorted, w.table);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
 }
@@ -312,19 +237,23 @@ int knn_self(int P, int K, const float *points, int *out_idx, float *out_dist, c
 int knn_dist2(int P, const float *points, float *mean_dists, char *workspace, hipStream_t stream) {
   if (P <= 0) return GSR_OK;
   KnnWorkspace w = knn_carve(workspace, (size_t)P);
-  const int nred = knn_red_blocks(P);
-  hipLaunchKernelGGL(aabb_partial_kernel, dim3(nred), dim3(256), 0, stream, P, points, w.partial);
-  hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(64), 0, stream, nred, w.partial, w.minmax);
-  hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, w.minmax, w.codes, w.idx);
-  GSR_LAUNCH_CHECK(stream, 0);
-  // 32-bit keys like the reference's SortPairs default (SK/simple_knn.cu:213): 4 passes, result in y = (codes_s, idx_s)
-  int rc = radix_sort_u32((size_t)P, w.codes, w.idx, w.tk, w.tv, w.codes_s, w.idx_s, 32, w.hist, stream, 0);
+  const int L = knn_level((size_t)P);
+  int rc = knn_build(P, points, w, L, stream);
   if (rc != GSR_OK) return rc;
-  const int nb = (P + KNN_BOX - 1) / KNN_BOX;
-  hipLaunchKernelGGL(gather_sorted_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, w.idx_s, w.sorted);
-  hipLaunchKernelGGL(box_minmax_kernel, dim3(nb), dim3(256), 0, stream, P, w.sorted, w.boxes);
-  hipLaunchKernelGGL(box_mean_dist_kernel, dim3((P + KNN_Q - 1) / KNN_Q), dim3(KNN_Q), 0, stream, P, w.sorted, w.idx_s,
-                     w.boxes, nb, mean_dists);
+  hipLaunchKernelGGL(grid_knn_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, P, 3, w.hdr, 1 << L, w.sorted, w.table,
+                     mean_dists, (int *)nullptr, (float *)nullptr);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
+int knn_self(int P, int K, const float *points, int *out_idx, float *out_dist, char *workspace, hipStream_t stream) {
+  if (P <= 0) return GSR_OK;
+  KnnWorkspace w = knn_carve(workspace, (size_t)P);
+  const int L = knn_level((size_t)P);
+  int rc = knn_build(P, points, w, L, stream);
+  if (rc != GSR_OK) return rc;
+  hipLaunchKernelGGL(grid_knn_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, P, K, w.hdr, 1 << L, w.sorted, w.table,
+                     (float *)nullptr, out_idx, out_dist);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
 }
