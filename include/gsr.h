@@ -239,6 +239,17 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
                      float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
                      float *dL_doff_pose, gsr_stream_t stream);
 
+/* Fused row gather over a structure of arrays (extension): the data movement of the reference's
+ * prune_points / cat_tensors_to_optimizer / densification_postfix (scene/gaussian_model.py:421-512) for ALL parameter
+ * tensors, both Adam moments of each and the statistics in one launch.  For every array a < n_arrays (<= 32; src / dst /
+ * row_floats / zero_new are HOST arrays, the pointers in them device pointers):
+ *   dst[a][j][:] = src[a][index[j] & 0x3FFFFFFF][:]          for j < n_out, rows of row_floats[a] floats,
+ *   dst[a][j][:] = 0   if index[j] < 0, or if bit 30 of index[j] is set ("new Gaussian") and zero_new[a] != 0
+ * (the Adam moments of cloned / split Gaussians start at zero, their parameters are copies of the parent's row).
+ * index is a device array; dst must not alias src. */
+int gsr_gather_rows(int n_arrays, const float *const *src, float *const *dst, const int *row_floats, const int *zero_new,
+                    int n_out, const int *index, gsr_stream_t stream);
+
 /* k-NN service replacing the un-vendored KNN_CUDA dependency (scene/gaussian_model.py:87-89).
  * Semantics assumed for KNN_CUDA 0.2 (parity unpinned): exact brute-force k-NN, Euclidean distances in ascending order;
  * here ties resolve to the lowest index.

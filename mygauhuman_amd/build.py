@@ -23,6 +23,7 @@ SOURCES = [
     ("attributes.hip", []),
     ("pose.hip", []),
     ("sh_exchange.hip", []),
+    ("rows.hip", []),
     ("loss.hip", []),
     ("gsr_api.hip", []),
 ]

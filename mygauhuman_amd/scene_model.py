@@ -23,7 +23,8 @@ class HumanGaussianModel:
         self.lweight_offset_decoder = None
         e = torch.empty(0, device=self.device)
         self._xyz = self._features_dc = self._features_rest = self._scaling = self._rotation = self._opacity = e
-        self._normal = self._albedo = e
+        self._normal = self._albedo = self._roughness = e
+        self.optimizer = None  # densify.training_setup() creates the Adam groups and the densification statistics
 
     @classmethod
     def from_points(cls, points, colors, sh_degree, dist2, smpl=None, motion_offset_flag=False, device="cuda"):
@@ -45,6 +46,7 @@ class HumanGaussianModel:
         m._scaling, m._rotation, m._opacity = req(scales), req(rots), req(opac)
         m._normal = req(F.normalize(torch.randn((P, 3), device=dev), dim=1))
         m._albedo = req(torch.zeros((P, 3), device=dev))
+        m._roughness = req(torch.zeros((P, 3), device=dev))
         return m
 
     @classmethod
@@ -64,6 +66,7 @@ class HumanGaussianModel:
         m._opacity = t(np.log(op / (1 - op)))
         m._normal = t(rng.normal(0, 1, (P, 3)).astype(np.float32))
         m._albedo = t(rng.normal(0, 1, (P, 3)).astype(np.float32))
+        m._roughness = t(rng.normal(0, 1, (P, 3)).astype(np.float32))
         return m
 
     # ---- the accessors render() uses (same names as the reference)
