@@ -239,6 +239,17 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
                      float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
                      float *dL_doff_pose, gsr_stream_t stream);
 
+/* Fused SSIM (extension): utils/loss_utils.py:25-66 -- 11x11 Gaussian window (sigma 1.5), zero
+ * padding, C1 = 0.01^2, C2 = 0.03^2 -- over `planes` independent H x W planes (batch x channels of the reference's grouped
+ * conv2d).  forward: ssim_map[planes][H][W] (may be null) and the three derivative maps dA, dB, dC (all three or none) that
+ * the backward consumes.  backward: dL_dimg1 from dL_dmap[planes][H][W], or from the constant dL_dmap_scalar when dL_dmap is
+ * null (the mean reduction of the reference: scalar = upstream / (planes * H * W)).  img2 is the ground truth: no gradient. */
+int gsr_ssim_forward(int planes, int height, int width, const float *img1, const float *img2, float *ssim_map, float *dA,
+                     float *dB, float *dC, gsr_stream_t stream);
+int gsr_ssim_backward(int planes, int height, int width, const float *img1, const float *img2, const float *dL_dmap,
+                      float dL_dmap_scalar, const float *dA, const float *dB, const float *dC, float *dL_dimg1,
+                      gsr_stream_t stream);
+
 /* Fused row gather over a structure of arrays (extension): the data movement of the reference's
  * prune_points / cat_tensors_to_optimizer / densification_postfix (scene/gaussian_model.py:421-512) for ALL parameter
  * tensors, both Adam moments of each and the statistics in one launch.  For every array a < n_arrays (<= 32; src / dst /

@@ -24,6 +24,7 @@ SOURCES = [
     ("pose.hip", []),
     ("sh_exchange.hip", []),
     ("rows.hip", []),
+    ("ssim.hip", []),
     ("loss.hip", []),
     ("gsr_api.hip", []),
 ]

@@ -1,0 +1,42 @@
+"""Fused SSIM kernels (csrc/ssim.hip) against the reference's grouped-conv2d formulation (utils/loss_utils.py:36-66, restated in
+mygauhuman_amd.loss_utils.ssim_torch and run in fp32 on the same device; the gradient also against float64)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 64, 64), (1, 3, 97, 131), (3, 40, 23), (2, 3, 11, 5), (1, 1, 300, 517)])
+def test_ssim_matches_reference_formulation(shape):
+    from mygauhuman_amd import loss_utils
+    g = torch.Generator().manual_seed(sum(shape))
+    img2 = torch.rand(shape, generator=g).cuda()
+    img1 = (img2 + 0.2 * torch.randn(shape, generator=g).cuda()).clamp(0, 1).requires_grad_(True)
+    ref1 = img1.detach().clone().requires_grad_(True)
+    v = loss_utils.ssim(img1, img2)
+    r = loss_utils.ssim_torch(ref1 if ref1.dim() == 4 else ref1[None], img2 if img2.dim() == 4 else img2[None])
+    assert abs(float(v.detach()) - float(r.detach())) < 2e-6
+    (1.0 - v).backward()
+    (1.0 - r).backward()
+    scale = float(ref1.grad.abs().max())
+    assert float((img1.grad - ref1.grad).abs().max()) < 1e-4 * scale
+    # float64 check of the gradient
+    d1 = img1.detach().double().requires_grad_(True)
+    r64 = loss_utils.ssim_torch(d1 if d1.dim() == 4 else d1[None], (img2 if img2.dim() == 4 else img2[None]).double())
+    (1.0 - r64).backward()
+    assert float((img1.grad.double() - d1.grad).abs().max()) < 2e-5 * scale
+
+
+def test_ssim_per_image_mode_identical_images_and_fallbacks():
+    from mygauhuman_amd import loss_utils
+    x = torch.rand((2, 3, 50, 60), device="cuda")
+    per = loss_utils.ssim(x, x.clone(), size_average=False)
+    assert per.shape == (2,) and torch.allclose(per, torch.ones(2, device="cuda"), atol=1e-6)
+    y = (x + 0.1).clamp(0, 1)
+    a = loss_utils.ssim(x, y, size_average=False)
+    b = loss_utils.ssim_torch(x, y, size_average=False)
+    assert torch.allclose(a, b, atol=2e-6)
+    # other window sizes and CPU tensors take the reference formulation
+    assert abs(float(loss_utils.ssim(x, y, window_size=7)) - float(loss_utils.ssim_torch(x, y, window_size=7))) < 1e-7
+    assert abs(float(loss_utils.ssim(x.cpu(), y.cpu())) - float(loss_utils.ssim_torch(x, y))) < 2e-6
