@@ -46,7 +46,7 @@ class HumanGaussianModel:
         m._scaling, m._rotation, m._opacity = req(scales), req(rots), req(opac)
         m._normal = req(F.normalize(torch.randn((P, 3), device=dev), dim=1))
         m._albedo = req(torch.zeros((P, 3), device=dev))
-        m._roughness = req(torch.zeros((P, 3), device=dev))
+        m._roughness = req(torch.ones((P, 1), device=dev))  # [P,1] like the reference (:241)
         return m
 
     @classmethod
@@ -66,7 +66,7 @@ class HumanGaussianModel:
         m._opacity = t(np.log(op / (1 - op)))
         m._normal = t(rng.normal(0, 1, (P, 3)).astype(np.float32))
         m._albedo = t(rng.normal(0, 1, (P, 3)).astype(np.float32))
-        m._roughness = t(rng.normal(0, 1, (P, 3)).astype(np.float32))
+        m._roughness = t(rng.normal(0, 1, (P, 1)).astype(np.float32))
         return m
 
     # ---- the accessors render() uses (same names as the reference)

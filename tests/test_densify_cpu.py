@@ -9,7 +9,7 @@ import torch
 from mygauhuman_amd import densify
 from oracle import densify_oracle as do
 
-SHAPES = dict(xyz=(3,), f_dc=(1, 3), f_rest=(15, 3), opacity=(1,), scaling=(3,), rotation=(4,), normal=(3,), albedo=(3,), roughness=(3,))
+SHAPES = dict(xyz=(3,), f_dc=(1, 3), f_rest=(15, 3), opacity=(1,), scaling=(3,), rotation=(4,), normal=(3,), albedo=(3,), roughness=(1,))
 
 
 def make_state(P, seed):
