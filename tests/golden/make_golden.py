@@ -95,6 +95,10 @@ def main():
                         w2v_translate_scale=w2v_ts, proj=proj, full_proj=full.numpy(), camera_center=center.numpy(),
                         fovx=np.float64(focal2fov(float(K[0, 0]), W)), fovy=np.float64(focal2fov(float(K[1, 1]), H)),
                         pts=pts, ndc=ndc)
+    # ---- the reference's own data file for the PLY reader / writer: check/points3d.ply (an SMPL-shaped initial point cloud,
+    # written by plyfile through storePly, scene/dataset_readers.py:138-153) is copied unchanged -- data, not source
+    import shutil
+    shutil.copyfile(os.path.join(REF, "check", "points3d.ply"), os.path.join(HERE, "points3d.ply"))
     print("golden vectors written to", HERE)
 
 
