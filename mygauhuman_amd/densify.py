@@ -99,7 +99,8 @@ def apply_plan(model, plan, reset_stats):
         for i, (kind, _, _, _) in enumerate(arrays):
             if kind == "stat":
                 outs[i].zero_()
-    move = [i for i, (kind, _, _, _) in enumerate(arrays) if not (kind == "stat" and reset_stats)]
+    # zero-width arrays (f_rest at SH degree 0) have nothing to move
+    move = [i for i, (kind, _, _, _) in enumerate(arrays) if not (kind == "stat" and reset_stats) and widths[i] > 0]
     if n_out and move:
         n = len(move)
         plan_c = plan.to(device=dev, dtype=torch.int32).contiguous()
