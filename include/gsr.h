@@ -301,6 +301,13 @@ int gsr_smpl_pose_backward(const float *poses, const float *correct_Rs, const fl
                            const float *dL_dA, const float *dL_drot_mats, float *dL_dposes, float *dL_dcorrect_Rs,
                            float *dL_djoints, gsr_stream_t stream);
 
+/* Row-major matrix-vector products for the SMPL pose blend shapes (scene/gaussian_model.py:805-811,827-839):
+ *   gsr_gemv_rows:   out[r] = sum_k mat[r][k] * vec[k]          (offsets[V*3] = posedirs[V*3][207] . pose_feature[207])
+ *   gsr_gemv_rows_t: dvec[k] = sum_r dout[r] * mat[r][k]        (its backward w.r.t. the pose feature; dvec is overwritten)
+ * cols <= 256. */
+int gsr_gemv_rows(int rows, int cols, const float *mat, const float *vec, float *out, gsr_stream_t stream);
+int gsr_gemv_rows_t(int rows, int cols, const float *mat, const float *dout, float *dvec, gsr_stream_t stream);
+
 /* Per-frame, per-Gaussian attributes render() derives between the LBS deform and the rasterizer
  * (gaussian_renderer/__init__.py:128-198; scene/gaussian_model.py:35-42,186-190; utils/general_utils.py:64-157;
  * utils/sh_utils.py:57-117; transform.py:9-17) -- one kernel instead of the reference's torch op chain.

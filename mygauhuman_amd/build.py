@@ -25,6 +25,7 @@ SOURCES = [
     ("sh_exchange.hip", []),
     ("rows.hip", []),
     ("ssim.hip", []),
+    ("gemv.hip", []),
     ("loss.hip", []),
     ("gsr_api.hip", []),
 ]

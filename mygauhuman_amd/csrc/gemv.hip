@@ -1,0 +1,88 @@
+// gemv.hip -- row-major matrix-vector products for the SMPL pose blend shapes: offsets[V*3] = posedirs[V*3][207] . feat[207]
+// (scene/gaussian_model.py:805-811,827-839).  rocBLAS runs this 17 MB GEMV at ~280 GB/s (60 us, twice per frame); it is
+// a pure HBM stream: one wave per run of rows, lane k reads elements k, k+64, ... of a row (coalesced 256-B segments at any
+// row alignment -- 207 is odd), a wave reduction per row.  The transposed product (the backward w.r.t. feat) keeps
+// per-lane column partials over the wave's rows and flushes them with one atomic per column per wave.
+#include "gsr_common.h"
+
+namespace gsr {
+
+constexpr int GEMV_KMAX = 256;       // columns handled (4 per lane)
+constexpr int GEMV_ROWS = 16;        // rows per wave
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gemv_rows_kernel(int R, int K, const float *mat, const float *vec, float *out) {
+  const int lane = threadIdx.x % WAVE, wave = (blockIdx.x * 256 + threadIdx.x) / WAVE;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) v[j] = (lane + 64 * j) < K ? vec[lane + 64 * j] : 0.f;
+  const int r0 = wave * GEMV_ROWS;
+  for (int r = r0; r < min(R, r0 + GEMV_ROWS); r++) {
+    const float *row = mat + (size_t)r * K;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (lane + 64 * j < K) acc += row[lane + 64 * j] * v[j];
+    acc = wave_sum(acc);
+    if (lane == 0) out[r] = acc;
+  }
+}
+
+// dvec[k] += sum_r dout[r] * mat[r][k]   (dvec zero-initialised by the caller)
+__global__ __launch_bounds__(256) void gemv_rows_t_kernel(int R, int K, const float *mat, const float *dout, float *dvec, int rows_per_wave) {
+  const int lane = threadIdx.x % WAVE, wave = (blockIdx.x * 256 + threadIdx.x) / WAVE;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int r0 = wave * rows_per_wave;
+  for (int r = r0; r < min(R, r0 + rows_per_wave); r++) {
+    const float *row = mat + (size_t)r * K;
+    const float g = dout[r];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (lane + 64 * j < K) acc[j] += g * row[lane + 64 * j];
+  }
+  if (r0 < R)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (lane + 64 * j < K) atomicAdd(&dvec[lane + 64 * j], acc[j]);
+}
+
+}  // namespace gsr
+
+extern "C" {
+
+int gsr_gemv_rows(int rows, int cols, const float *mat, const float *vec, float *out, gsr_stream_t stream_) {
+  using namespace gsr;
+  if (rows < 0 || cols < 1 || cols > GEMV_KMAX || (rows > 0 && (!mat || !vec || !out))) {
+    set_error("gsr_gemv_rows: bad arguments (1..%d columns)", GEMV_KMAX);
+    return GSR_EINVAL;
+  }
+  if (rows == 0) return GSR_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int waves = (rows + GEMV_ROWS - 1) / GEMV_ROWS;
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, rows, cols, mat, vec, out);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
+int gsr_gemv_rows_t(int rows, int cols, const float *mat, const float *dout, float *dvec, gsr_stream_t stream_) {
+  using namespace gsr;
+  if (rows < 0 || cols < 1 || cols > GEMV_KMAX || (rows > 0 && (!mat || !dout)) || !dvec) {
+    set_error("gsr_gemv_rows_t: bad arguments (1..%d columns)", GEMV_KMAX);
+    return GSR_EINVAL;
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  GSR_HIP(hipMemsetAsync(dvec, 0, sizeof(float) * cols, stream));
+  if (rows == 0) return GSR_OK;
+  const int rows_per_wave = 48;
+  const int waves = (rows + rows_per_wave - 1) / rows_per_wave;
+  hipLaunchKernelGGL(gemv_rows_t_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, rows, cols, mat, dout, dvec, rows_per_wave);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
+}  // extern "C"

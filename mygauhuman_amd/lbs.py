@@ -63,13 +63,43 @@ def get_transform_params_torch(smpl, params, rot_mats=None, correct_Rs=None):
     return A, params["R"], params["Th"], joints
 
 
+class _RowGemv(torch.autograd.Function):
+    """out[R] = mat[R,K] @ vec[K] with the HIP GEMV (csrc/gemv.hip); gradient w.r.t. vec only (mat = constant blend shapes)."""
+
+    @staticmethod
+    def forward(ctx, mat, vec):
+        dev = mat.device
+        m, v = mat.detach().contiguous().float(), vec.detach().contiguous().float()
+        out = torch.empty((m.shape[0],), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gsr_gemv_rows(m.shape[0], m.shape[1], ptr(m), ptr(v), ptr(out), torch.cuda.current_stream(dev).cuda_stream),
+                  "gsr_gemv_rows")
+        ctx.save_for_backward(m)
+        ctx.vshape = vec.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        dv = torch.empty((m.shape[1],), dtype=torch.float32, device=m.device)
+        g = g.contiguous().float()
+        with torch.cuda.device(m.device):
+            check(lib.gsr_gemv_rows_t(m.shape[0], m.shape[1], ptr(m), ptr(g), ptr(dv), torch.cuda.current_stream(m.device).cuda_stream),
+                  "gsr_gemv_rows_t")
+        return None, dv.view(ctx.vshape)
+
+
 def pose_offsets(smpl, rot_mats):
-    """(R[1:] - I).flatten() [1,207] @ posedirs^T -> per-vertex offsets [V,3] (gaussian_model.py:805-811,827-839)."""
+    """(R[1:] - I).flatten() [1,207] @ posedirs^T -> per-vertex offsets [V,3] (gaussian_model.py:805-811,827-839).
+    GPU tensors: one HBM-streaming HIP GEMV (rocBLAS needs 60 us for this 17 MB product); CPU tensors: torch.matmul."""
     posedirs = smpl["posedirs"]
     V = smpl["v_template"].shape[0]
     ident = torch.eye(3, dtype=rot_mats.dtype, device=rot_mats.device)
     feat = (rot_mats[:, 1:] - ident).reshape(rot_mats.shape[0], -1)
-    return torch.matmul(feat, posedirs.reshape(V * 3, -1).t()).view(-1, V, 3)[0]
+    pd = posedirs.reshape(V * 3, -1)
+    if pd.is_cuda and feat.shape[0] == 1 and pd.shape[1] <= 256 and pd.dtype == torch.float32:
+        return _RowGemv.apply(pd, feat[0]).view(V, 3)
+    return torch.matmul(feat, pd.t()).view(-1, V, 3)[0]
 
 
 def shape_offsets(smpl, shapes):

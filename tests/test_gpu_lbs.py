@@ -233,3 +233,19 @@ def test_smpl_pose_kernel_matches_torch_chain(oracle, with_correct):
     assert torch.equal(A[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev).expand(24, 4))
     with pytest.raises(RuntimeError):
         lbs._SmplPose.apply(poses, cr, joints, (0,) + tuple(range(1, 24)))  # parents[1] = 1 does not precede joint 1
+
+
+@pytest.mark.parametrize("R,K", [(20670, 207), (1, 1), (1000, 256), (37, 64), (16, 65)])
+def test_row_gemv_forward_backward(R, K):
+    """csrc/gemv.hip (pose blend-shape product) against torch.matmul in float64."""
+    from mygauhuman_amd import lbs
+    g = torch.Generator().manual_seed(R + K)
+    mat = torch.randn((R, K), generator=g).cuda()
+    vec = torch.randn((K,), generator=g).cuda().requires_grad_(True)
+    w = torch.randn((R,), generator=g).cuda()
+    out = lbs._RowGemv.apply(mat, vec)
+    (out * w).sum().backward()
+    ref = mat.double() @ vec.detach().double()
+    dref = mat.double().t() @ w.double()
+    assert float((out.detach().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max() + 1e-30)
+    assert float((vec.grad.double() - dref).abs().max()) <= 2e-5 * float(dref.abs().max() + 1e-30)
