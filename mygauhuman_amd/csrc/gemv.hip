@@ -8,7 +8,7 @@
 namespace gsr {
 
 constexpr int GEMV_KMAX = 256;       // columns handled (4 per lane)
-constexpr int GEMV_ROWS = 16;        // rows per wave
+constexpr int GEMV_ROWS = 4;         // rows per wave, all loaded before the first reduction (16 loads in flight per lane)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -22,15 +22,21 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int R, int K, const floa
 #pragma unroll
   for (int j = 0; j < 4; j++) v[j] = (lane + 64 * j) < K ? vec[lane + 64 * j] : 0.f;
   const int r0 = wave * GEMV_ROWS;
-  for (int r = r0; r < min(R, r0 + GEMV_ROWS); r++) {
-    const float *row = mat + (size_t)r * K;
-    float acc = 0.f;
+  if (r0 >= R) return;
+  float m[GEMV_ROWS][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (lane + 64 * j < K) acc += row[lane + 64 * j] * v[j];
-    acc = wave_sum(acc);
-    if (lane == 0) out[r] = acc;
+  for (int u = 0; u < GEMV_ROWS; u++) {
+    const float *row = mat + (size_t)min(r0 + u, R - 1) * K;
+#pragma unroll
+    for (int j = 0; j < 4; j++) m[u][j] = (lane + 64 * j < K) ? row[lane + 64 * j] : 0.f;
   }
+  float mine = 0.f;
+#pragma unroll
+  for (int u = 0; u < GEMV_ROWS; u++) {
+    const float acc = wave_sum((m[u][0] * v[0] + m[u][1] * v[1]) + (m[u][2] * v[2] + m[u][3] * v[3]));
+    mine = lane == u ? acc : mine;
+  }
+  if (lane < GEMV_ROWS && r0 + lane < R) out[r0 + lane] = mine;
 }
 
 // dvec[k] += sum_r dout[r] * mat[r][k]   (dvec zero-initialised by the caller)

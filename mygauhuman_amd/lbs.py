@@ -165,10 +165,18 @@ def smpl_pose_transforms(smpl, params, correct_Rs=None):
     """HIP counterpart of batch_rodrigues + get_transform_params_torch for batch size 1:
     returns (A [1,24,4,4], rot_mats [1,24,3,3], joints [1,24,3])."""
     betas = params["shapes"]
-    V = smpl["v_template"].shape[0]
-    sd = smpl["shapedirs"][..., :betas.shape[-1]]
-    v_shaped = smpl["v_template"] + torch.matmul(sd.reshape(V * 3, -1), betas.reshape(-1, 1).float()).view(V, 3)
-    joints = torch.matmul(smpl["J_regressor"], v_shaped)
+    nb = int(betas.shape[-1])
+    # joints = J_regressor (v_template + shapedirs beta) = J_template + J_shapedirs beta: the two regressed tables are
+    # constants of the SMPL model and are cached on the dict (the per-frame [24 x 6890] x [6890 x 3] product is a one-tile,
+    # K = 6890 rocBLAS launch of 60 us)
+    cache = smpl.get("_joint_tables")
+    if cache is None or cache[0] != nb:
+        with torch.no_grad():
+            Jt = torch.matmul(smpl["J_regressor"], smpl["v_template"])                                       # [24, 3]
+            Js = torch.einsum("jv,vcl->jcl", smpl["J_regressor"], smpl["shapedirs"][..., :nb].float())       # [24, 3, nb]
+        cache = (nb, Jt.contiguous(), Js.contiguous())
+        smpl["_joint_tables"] = cache
+    joints = cache[1] + torch.matmul(cache[2], betas.reshape(-1, 1).float()).squeeze(-1)
     rot, A = _SmplPose.apply(params["poses"], correct_Rs, joints, parents_host(smpl))
     return A[None], rot[None], joints[None]
 
@@ -224,14 +232,18 @@ class _LBSDeform(torch.autograd.Function):
         d_query = torch.empty((P, 3), dtype=f32, device=dev)
         d_normals = torch.empty((P, 3), dtype=f32, device=dev) if normals is not None else None
         d_loff = torch.empty((P, 24), dtype=f32, device=dev) if loff is not None else None
-        d_A = torch.zeros((24, 16), dtype=f32, device=dev)
-        d_off = torch.zeros((V, 3), dtype=f32, device=dev)
+        # A_pose / off_pose gradients only when the pose path is trainable (pose-refinement MLP): their reductions are atomics
+        # of every workgroup onto 288 + 3V addresses
+        need_A, need_off = ctx.needs_input_grad[4], ctx.needs_input_grad[7]
+        d_A = torch.zeros((24, 16), dtype=f32, device=dev) if need_A else None
+        d_off = torch.zeros((V, 3), dtype=f32, device=dev) if need_off else None
         with torch.cuda.device(dev):
             check(lib.gsr_lbs_backward(P, V, ptr(query), ptr(normals), ptr(vert_ids), ptr(w), ptr(loff), ptr(A_big), ptr(A_pose),
                                        ptr(ob), ptr(os_), ptr(op), ptr(R), ptr(g_world), ptr(g_transforms), ptr(g_normals),
                                        ptr(d_query), ptr(d_normals), ptr(d_loff), ptr(d_A), ptr(d_off),
                                        torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_backward")
-        return (d_query, d_normals, d_loff, None, d_A.view(A_shape), None, None, d_off.view(off_shape_), None, None, None, None)
+        return (d_query, d_normals, d_loff, None, None if d_A is None else d_A.view(A_shape), None, None,
+                None if d_off is None else d_off.view(off_shape_), None, None, None, None)
 
 
 def lbs_deform(query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights):
