@@ -218,14 +218,17 @@ int gsr_lbs_forward(int P, int V, const float *query, const float *normals, cons
 /* Same results as gsr_lbs_forward, bit for bit, with the nearest-vertex search run through a uniform grid over the V
  * reference vertices (rebuilt on every call by one workgroup) instead of the brute-force scan: ~30x fewer distance
  * evaluations when the query points lie near the vertex cloud, as canonical Gaussians do.  `workspace` must hold
- * gsr_lbs_workspace_bytes(V) bytes, 16-byte aligned. */
+ * gsr_lbs_workspace_bytes(V) bytes, 16-byte aligned.  grid_is_built != 0: the workspace already holds the grid of exactly
+ * these vertices (gsr_lbs_grid_build, or an earlier call) and the rebuild is skipped -- the big-pose vertices of a subject
+ * never change between frames. */
 size_t gsr_lbs_workspace_bytes(int V);
+int gsr_lbs_grid_build(int V, const float *smpl_verts, char *workspace, size_t workspace_bytes, gsr_stream_t stream);
 int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals, const float *smpl_verts,
                          const float *weights, const float *lbs_offsets, const float *A_big, const float *A_pose,
                          const float *off_big, const float *off_shape, const float *off_pose, const float *R,
                          const float *Th, int *vert_ids, float *bweights, float *smpl_pts, float *world_pts,
                          float *transforms, float *translation, float *world_normals, char *workspace,
-                         size_t workspace_bytes, gsr_stream_t stream);
+                         size_t workspace_bytes, int grid_is_built, gsr_stream_t stream);
 
 /* Backward of gsr_lbs_forward w.r.t. query, normals, lbs_offsets, A_pose, off_pose (A_big/off_big/off_shape
  * belong to the constant big pose / shape and get no gradient in the reference training loop).

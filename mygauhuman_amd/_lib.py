@@ -21,7 +21,7 @@ SYMBOLS = [
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
-    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_workspace_bytes", "gsr_lbs_forward_grid", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward",
+    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward",
 ]
 
 GSR_OK = 0
@@ -86,7 +86,9 @@ def _load():
     lib.gsr_sort_pairs_u64.argtypes = [sz, vp, vp, vp, vp, C.c_int, vp, sz, vp]
     lib.gsr_sort_pairs_u32.argtypes = [sz, vp, vp, vp, vp, C.c_int, vp, sz, vp]
     lib.gsr_lbs_forward.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp]
-    lib.gsr_lbs_forward_grid.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp, sz, vp]
+    lib.gsr_lbs_forward_grid.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp, sz, C.c_int, vp]
+    lib.gsr_lbs_grid_build.argtypes = [C.c_int, fp, vp, sz, vp]
+    lib.gsr_lbs_grid_build.restype = C.c_int
     lib.gsr_lbs_forward_grid.restype = C.c_int
     lib.gsr_lbs_workspace_bytes.argtypes = [C.c_int]
     lib.gsr_lbs_workspace_bytes.restype = sz

@@ -277,16 +277,32 @@ __device__ __forceinline__ void blend_weights(const float *w_row, const float *o
 __device__ __forceinline__ void blend_A(const float *bw, const float *sA, float *out) {
 #pragma unroll
   for (int k = 0; k < 12; k++) out[k] = 0.f;
-#pragma unroll
-  for (int j = 0; j < NJ; j++)
-#pragma unroll
-    for (int k = 0; k < 12; k++) out[k] += bw[j] * sA[16 * j + k];
+  // joints two at a time: fully unrolled, the 24 x 12 LDS operands get hoisted and the kernel ends up at 256 VGPRs + scratch
+#pragma unroll 2
+  for (int j = 0; j < NJ; j++) {
+    const float4 r0 = *reinterpret_cast<const float4 *>(&sA[16 * j]);
+    const float4 r1 = *reinterpret_cast<const float4 *>(&sA[16 * j + 4]);
+    const float4 r2 = *reinterpret_cast<const float4 *>(&sA[16 * j + 8]);
+    const float b = bw[j];
+    out[0] += b * r0.x;
+    out[1] += b * r0.y;
+    out[2] += b * r0.z;
+    out[3] += b * r0.w;
+    out[4] += b * r1.x;
+    out[5] += b * r1.y;
+    out[6] += b * r1.z;
+    out[7] += b * r1.w;
+    out[8] += b * r2.x;
+    out[9] += b * r2.y;
+    out[10] += b * r2.z;
+    out[11] += b * r2.w;
+  }
 }
 
 template <bool GRID>
 __global__ __launch_bounds__(LBS_BLOCK) void lbs_forward_kernel(const LbsArgs a) {
   __shared__ float svx[GRID ? 1 : VTILE], svy[GRID ? 1 : VTILE], svz[GRID ? 1 : VTILE];
-  __shared__ float sAb[NJ * 16], sAp[NJ * 16];
+  __shared__ __attribute__((aligned(16))) float sAb[NJ * 16], sAp[NJ * 16];
   const int p = blockIdx.x * LBS_BLOCK + threadIdx.x;
   const bool live = p < a.P;
   for (int k = threadIdx.x; k < NJ * 16; k += LBS_BLOCK) {
@@ -393,7 +409,7 @@ struct LbsBwdArgs {
 };
 
 __global__ __launch_bounds__(LBS_BLOCK) void lbs_backward_kernel(const LbsBwdArgs a) {
-  __shared__ float sAb[NJ * 16], sAp[NJ * 16];
+  __shared__ __attribute__((aligned(16))) float sAb[NJ * 16], sAp[NJ * 16];
   constexpr int ROW = NJ + 12 + 1;                // bw[24] | g_Ap[12] | pad (odd stride: conflict-free column reads)
   __shared__ float s_rows[LBS_BLOCK * ROW];       // per-point operands of the workgroup-level dA_pose product
   for (int k = threadIdx.x; k < NJ * 16; k += LBS_BLOCK) {
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(LBS_BLOCK) void lbs_backward_kernel(const LbsBwdArg
     const float g_Ap[12] = {g_Rp[0], g_Rp[1], g_Rp[2], g_tp[0], g_Rp[3], g_Rp[4], g_Rp[5], g_tp[1], g_Rp[6], g_Rp[7], g_Rp[8], g_tp[2]};
     // dA_pose[j][k] += bw[j] g_Ap[k]  (workgroup-level LDS accumulation) ; g_bw[j] = <g_Ab, A_big[j]> + <g_Ap, A_pose[j]>
     float g_bw[NJ];
-#pragma unroll
+#pragma unroll 2
     for (int j = 0; j < NJ; j++) {
       float s = 0.f;
 #pragma unroll
@@ -565,6 +581,18 @@ int gsr_lbs_forward(int P, int V, const float *query, const float *normals, cons
 
 size_t gsr_lbs_workspace_bytes(int V) { return V > 0 ? gsr::grid_workspace_bytes(V) : 0; }
 
+int gsr_lbs_grid_build(int V, const float *smpl_verts, char *workspace, size_t workspace_bytes, gsr_stream_t stream_) {
+  if (V <= 0 || !smpl_verts || !workspace || workspace_bytes < gsr::grid_workspace_bytes(V) ||
+      reinterpret_cast<size_t>(workspace) % 16 != 0) {
+    gsr::set_error("gsr_lbs_grid_build: bad arguments (workspace of %zu bytes, 16-byte aligned)", gsr::grid_workspace_bytes(V > 0 ? V : 1));
+    return GSR_EINVAL;
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(gsr::lbs_grid_build_kernel, dim3(1), dim3(gsr::GRID_BLOCK), 0, stream, V, smpl_verts, workspace);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
 int gsr_knn_nearest(int M, const float *query, int N, const float *ref, int *idx, float *dist, char *workspace,
                     size_t workspace_bytes, gsr_stream_t stream_) {
   if (M < 0 || N <= 0 || !ref || (M > 0 && (!query || (!idx && !dist)))) {
@@ -588,7 +616,7 @@ int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals,
                          const float *lbs_offsets, const float *A_big, const float *A_pose, const float *off_big,
                          const float *off_shape, const float *off_pose, const float *R, const float *Th, int *vert_ids,
                          float *bweights, float *smpl_pts, float *world_pts, float *transforms, float *translation,
-                         float *world_normals, char *workspace, size_t workspace_bytes, gsr_stream_t stream_) {
+                         float *world_normals, char *workspace, size_t workspace_bytes, int grid_is_built, gsr_stream_t stream_) {
   if (P < 0 || V <= 0 || (P > 0 && (!query || !smpl_verts || !weights || !A_big || !A_pose || !off_big || !off_shape ||
                                     !off_pose || !R || !Th || !world_pts))) {
     gsr::set_error("gsr_lbs_forward_grid: bad arguments");
@@ -601,7 +629,8 @@ int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals,
     return GSR_EINVAL;
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(gsr::lbs_grid_build_kernel, dim3(1), dim3(gsr::GRID_BLOCK), 0, stream, V, smpl_verts, workspace);
+  if (!grid_is_built)
+    hipLaunchKernelGGL(gsr::lbs_grid_build_kernel, dim3(1), dim3(gsr::GRID_BLOCK), 0, stream, V, smpl_verts, workspace);
   gsr::LbsArgs a = {P, V, query, normals, smpl_verts, weights, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th,
                     vert_ids, bweights, smpl_pts, world_pts, transforms, translation, world_normals, workspace};
   hipLaunchKernelGGL(gsr::lbs_forward_kernel<true>, dim3((P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK), dim3(gsr::LBS_BLOCK), 0,

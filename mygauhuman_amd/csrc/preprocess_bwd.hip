@@ -72,8 +72,7 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
     for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
     if (a.shs)
       for (int k = 0; k < a.M * 3; k++) dsh_out[k] = 0.f;
-    for (int c = 0; c < a.CE; c++) a.dL_dextra[(size_t)i * a.CE + c] = 0.f;
-    return;
+    return;  // (the extra-channel gradients of the whole workgroup are copied cooperatively by the kernel)
   }
   const float4 *row = reinterpret_cast<const float4 *>(a.grad_rows + (size_t)i * a.grow);
   const float4 m0 = row[0], m1 = row[1], m2 = row[2];
@@ -104,8 +103,6 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
   a.dL_dcolor[3 * (size_t)i + 1] = g1.w;
   a.dL_dcolor[3 * (size_t)i + 2] = g2.x;
   const float dcx = g0.z, dcy = g0.w, dcz = g1.x;
-  for (int c = 0; c < a.CE; c++)  // fused multi-feature blend: colour gradients of the extra channels pass straight through
-    a.dL_dextra[(size_t)i * a.CE + c] = a.grad_rows[(size_t)i * a.grow + 9 + c];
 
   const float *vm = a.view, *proj = a.proj;
   const float3 mean = make_float3(a.means3D[3 * (size_t)i], a.means3D[3 * (size_t)i + 1], a.means3D[3 * (size_t)i + 2]);
@@ -222,6 +219,19 @@ template <bool STAGE_SH>
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? 256 * BSH_LDS_ROW : 4];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (a.CE > 0) {
+    // fused multi-feature blend: the colour gradients of the extra channels pass straight through, columns 9.. of the
+    // gradient rows -> dL_dextra[P][CE]; the workgroup's 256 rows are contiguous on both sides, so the copy is cooperative
+    // (coalesced stores); rows of culled Gaussians were never touched by an atomic and are still zero
+    const int first = blockIdx.x * 256;
+    const int nrows = min(256, a.P - first);
+    const float *src = a.grad_rows + (size_t)first * a.grow + 9;
+    float *dst = a.dL_dextra + (size_t)first * a.CE;
+    for (int e = threadIdx.x; e < nrows * a.CE; e += 256) {
+      const int r = e / a.CE, c = e - r * a.CE;
+      dst[e] = src[(size_t)r * a.grow + c];
+    }
+  }
   if (STAGE_SH) {
     const int first = blockIdx.x * 256;
     const int nrows = min(256, a.P - first);

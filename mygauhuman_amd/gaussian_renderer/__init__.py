@@ -33,7 +33,7 @@ def _deform(pc, means3D, normal, cam, lbs_weights=None, correct_Rs=None, return_
     if isinstance(smpl, dict) and "kintree_table" in smpl:
         return _lbs.coarse_deform_c2source(smpl, means3D[None], cam.smpl_param, cam.big_pose_smpl_param,
                                            cam.big_pose_world_vertex[None], lbs_weights=lbs_weights, correct_Rs=correct_Rs,
-                                           return_transl=return_transl, normals=normal[None])
+                                           return_transl=return_transl, normals=normal[None], lean=True)
     raise RuntimeError("render(): pc.SMPL_NEUTRAL (device tensors incl. kintree_table) is required for the LBS deform")
 
 

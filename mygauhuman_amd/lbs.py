@@ -185,9 +185,36 @@ POSE_CHAIN = "hip"              # "hip" (csrc/pose.hip, default) or "torch" (the
 NEAREST_VERTEX_SEARCH = "grid"  # "grid" (uniform vertex grid, default) or "brute"; identical results
 
 
+class _VertexGridCache:
+    """Grid workspaces of reference-vertex tensors that were seen before.  The big-pose vertices of a subject are the same
+    tensor frame after frame (one per camera, scene/cameras.py:72), so their 46 us single-workgroup grid build is done once.
+    Key = (storage address, tensor version, shape): any in-place change bumps the version; the entry holds a reference to the
+    tensor, so its address cannot be handed to another tensor while the entry lives.  Memory: ~0.7 MB per entry, LRU."""
+
+    def __init__(self, capacity=1024):
+        from collections import OrderedDict
+        self.capacity, self.entries = capacity, OrderedDict()
+
+    def get(self, verts):
+        key = (verts.data_ptr(), verts._version, tuple(verts.shape), str(verts.device))
+        hit = self.entries.get(key)
+        if hit is not None:  # hit[0] keeps the storage alive, so the address cannot belong to different data at this version
+            self.entries.move_to_end(key)
+            return hit[1], True
+        ws = torch.empty((lib.gsr_lbs_workspace_bytes(verts.shape[0]),), dtype=torch.uint8, device=verts.device)
+        self.entries[key] = (verts, ws)
+        if len(self.entries) > self.capacity:
+            self.entries.popitem(last=False)
+        return ws, False
+
+
+_GRIDS = _VertexGridCache()
+
+
 class _LBSDeform(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights):
+    def forward(ctx, query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights,
+                lean=False):
         if not query.is_cuda:
             raise RuntimeError("LBS deform: tensors must live on a HIP device (no CPU path)")
         dev, f32 = query.device, torch.float32
@@ -198,11 +225,12 @@ class _LBSDeform(torch.autograd.Function):
         ob, os_, op = c(off_big), c(off_shape), c(off_pose)
         R_c, Th_c, sv, w = c(R).reshape(3, 3), c(Th).reshape(3), c(smpl_verts), c(weights)
         vert_ids = torch.empty((P,), dtype=torch.int32, device=dev)
-        bweights = torch.empty((P, 24), dtype=f32, device=dev)
-        smpl_pts = torch.empty((P, 3), dtype=f32, device=dev)
+        # lean: the caller (render()) only consumes world points / transforms / normals: skip 120 B per point of stores
+        bweights = None if lean else torch.empty((P, 24), dtype=f32, device=dev)
+        smpl_pts = None if lean else torch.empty((P, 3), dtype=f32, device=dev)
         world_pts = torch.empty((P, 3), dtype=f32, device=dev)
         transforms = torch.empty((P, 3, 3), dtype=f32, device=dev)
-        translation = torch.empty((P, 3), dtype=f32, device=dev)
+        translation = None if lean else torch.empty((P, 3), dtype=f32, device=dev)
         world_normals = torch.empty((P, 3), dtype=f32, device=dev) if normals is not None else None
         args = (P, V, ptr(query_c), ptr(normals_c), ptr(sv), ptr(w), ptr(loff), ptr(A_big_c), ptr(A_pose_c), ptr(ob), ptr(os_),
                 ptr(op), ptr(R_c), ptr(Th_c), ptr(vert_ids), ptr(bweights), ptr(smpl_pts), ptr(world_pts), ptr(transforms),
@@ -210,12 +238,18 @@ class _LBSDeform(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if NEAREST_VERTEX_SEARCH == "grid":
-                ws = torch.empty((lib.gsr_lbs_workspace_bytes(V),), dtype=torch.uint8, device=dev)
-                check(lib.gsr_lbs_forward_grid(*args, ptr(ws), ws.numel(), stream), "gsr_lbs_forward_grid")
+                if sv.data_ptr() == smpl_verts.data_ptr():   # the caller's own storage (no conversion copy): remember its grid
+                    ws, built = _GRIDS.get(smpl_verts)
+                else:
+                    ws, built = torch.empty((lib.gsr_lbs_workspace_bytes(V),), dtype=torch.uint8, device=dev), False
+                check(lib.gsr_lbs_forward_grid(*args, ptr(ws), ws.numel(), int(built), stream), "gsr_lbs_forward_grid")
             else:
                 check(lib.gsr_lbs_forward(*args, stream), "gsr_lbs_forward")
         ctx.save_for_backward(query_c, normals_c, loff, A_big_c, A_pose_c, ob, os_, op, R_c, vert_ids, w)
         ctx.shapes = (A_pose.shape, off_pose.shape, V)
+        e = torch.empty(0, device=dev)
+        smpl_pts, bweights, translation = (e if smpl_pts is None else smpl_pts, e if bweights is None else bweights,
+                                           e if translation is None else translation)
         ctx.mark_non_differentiable(vert_ids, bweights, smpl_pts, translation)
         return (world_pts, transforms, world_normals if world_normals is not None else torch.empty(0, device=dev), smpl_pts,
                 bweights, translation, vert_ids)
@@ -243,18 +277,19 @@ class _LBSDeform(torch.autograd.Function):
                                        ptr(d_query), ptr(d_normals), ptr(d_loff), ptr(d_A), ptr(d_off),
                                        torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_backward")
         return (d_query, d_normals, d_loff, None, None if d_A is None else d_A.view(A_shape), None, None,
-                None if d_off is None else d_off.view(off_shape_), None, None, None, None)
+                None if d_off is None else d_off.view(off_shape_), None, None, None, None, None)
 
 
-def lbs_deform(query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights):
-    """Per-point LBS (HIP). Returns dict(world_pts, transforms, world_normals, smpl_pts, bweights, translation, vert_ids)."""
-    o = _LBSDeform.apply(query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights)
+def lbs_deform(query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights, lean=False):
+    """Per-point LBS (HIP). Returns dict(world_pts, transforms, world_normals, smpl_pts, bweights, translation, vert_ids);
+    lean=True leaves smpl_pts / bweights / translation empty (not computed)."""
+    o = _LBSDeform.apply(query, normals, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th, smpl_verts, weights, lean)
     return dict(world_pts=o[0], transforms=o[1], world_normals=o[2] if normals is not None else None, smpl_pts=o[3],
                 bweights=o[4], translation=o[5], vert_ids=o[6])
 
 
 def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_weights=None, correct_Rs=None,
-                           return_transl=False, normals=None):
+                           return_transl=False, normals=None, lean=False):
     """Drop-in for GaussianModel.coarse_deform_c2source (batch size 1): same arguments after `smpl`
     (= self.SMPL_NEUTRAL as device tensors) and the same 6-tuple
     (smpl_src_pts[1,P,3], world_src_pts[1,P,3], bweights[1,P,24], transforms[1,P,3,3], translation|None, world_normals)."""
@@ -277,7 +312,7 @@ def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_we
     off_pose = pose_offsets(smpl, rot_mats)
     o = lbs_deform(query_pts[0], None if normals is None else normals[0], None if lbs_weights is None else lbs_weights[0],
                    A_big[0], A_pose[0], off_big, off_shape, off_pose, R.reshape(3, 3), Th.reshape(-1)[:3], t_vertices[0],
-                   smpl["weights"])
+                   smpl["weights"], lean=lean and not return_transl)
     translation = o["translation"][None] if return_transl else None
     wn = None if o["world_normals"] is None else o["world_normals"][None]
     return o["smpl_pts"][None], o["world_pts"][None], o["bweights"][None], o["transforms"][None], translation, wn

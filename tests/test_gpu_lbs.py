@@ -249,3 +249,31 @@ def test_row_gemv_forward_backward(R, K):
     dref = mat.double().t() @ w.double()
     assert float((out.detach().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max() + 1e-30)
     assert float((vec.grad.double() - dref).abs().max()) <= 2e-5 * float(dref.abs().max() + 1e-30)
+
+
+def test_vertex_grid_cache_reuse_and_invalidation(oracle):
+    """The cached grid must be reused for the same vertex tensor and rebuilt after an in-place change of the vertices."""
+    from mygauhuman_amd import lbs
+    c = make_case(oracle, 700, 10, 5, False)
+    rng = np.random.default_rng(0)
+    verts = torch.from_numpy((rng.uniform(-1, 1, (2000, 3))).astype(np.float32)).cuda()
+    query = (verts[rng.integers(0, 2000, 3000)] + 0.01 * torch.randn(3000, 3, device="cuda")).contiguous()
+    d = util.to_dev
+    w = d(np.full((2000, 24), 1 / 24, np.float32))
+    z = d(np.zeros((2000, 3), np.float32))
+
+    def ids():
+        return lbs.lbs_deform(query, None, None, d(c["A_big"]), d(c["A_pose"]), z, z, z, d(c["R"]), d(c["Th"]), verts, w, lean=True)["vert_ids"].cpu().numpy()
+    n0 = len(lbs._GRIDS.entries)
+    a = ids()
+    n1 = len(lbs._GRIDS.entries)
+    b = ids()
+    assert n1 == n0 + 1 and len(lbs._GRIDS.entries) == n1          # second call reused the entry
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, oracle.nearest_vertex(query.cpu().numpy(), verts.cpu().numpy()))
+    verts.mul_(-1.0)                                               # in-place change: version bump -> new grid
+    e = ids()
+    assert len(lbs._GRIDS.entries) == n1 + 1
+    np.testing.assert_array_equal(e, oracle.nearest_vertex(query.cpu().numpy(), verts.cpu().numpy()))
+    out = lbs.lbs_deform(query, None, None, d(c["A_big"]), d(c["A_pose"]), z, z, z, d(c["R"]), d(c["Th"]), verts, w, lean=True)
+    assert out["bweights"].numel() == 0 and out["smpl_pts"].numel() == 0 and out["world_pts"].shape == (3000, 3)
