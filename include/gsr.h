@@ -48,17 +48,23 @@ int gsr_version(void);
 const char *gsr_target_arch(void);
 const char *gsr_last_error(void);
 
-/* Binning back-ends (gsr_set_binning_mode): both produce bit-identical point lists and tile ranges.
+/* Binning back-ends (gsr_set_binning_mode; default GSR_BINNING_TILE_BUCKET):
  *   GSR_BINNING_GLOBAL_RADIX: duplicate keys + device-wide stable LSD radix sort on the low 32+bit key bits +
  *                             identifyTileRanges -- the reference's structure (CR/rasterizer_impl.cu:291-320);
- *   GSR_BINNING_TILE_BUCKET : per-tile counting + per-tile LDS sort on (depth bits, Gaussian id). */
+ *   GSR_BINNING_TILE_BUCKET : per-tile counting + per-tile register / LDS sort on (depth bits, Gaussian id).
+ * With the tuning knob "tile_cull" = 0 both produce the reference's point lists and tile ranges bit for bit.  With
+ * "tile_cull" = 1 (default, tile-bucket only) instances whose tile the Gaussian cannot reach with alpha >= 1/255 are dropped:
+ * images, radii and gradients are unchanged, the per-tile lists are sublists of the reference's. */
 #define GSR_BINNING_GLOBAL_RADIX 0
 #define GSR_BINNING_TILE_BUCKET 1
 int gsr_set_binning_mode(int mode);
 int gsr_get_binning_mode(void);
 
-/* Performance knobs that never change results: "blend_fwd_waves" / "blend_bwd_waves" in {1, 2, 4} = waves that
- * cooperate on one 16x16 tile (each lane then owns 4 / waves pixels). */
+/* Performance knobs (images, radii and gradients never change):
+ *   "blend_fwd_waves" / "blend_bwd_waves" in {1, 2, 4}: waves that cooperate on one 16x16 tile (a lane owns 4 / waves pixels);
+ *   "blend_bwd_reduce" in {0, 1}: cross-lane reduction of the backward on the VALU (DPP / permlane, default) or through MFMA;
+ *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the tile-bucket back-end;
+ *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above). */
 int gsr_set_tuning(const char *key, int value);
 
 /* Optional stage timing with HIP events recorded on the caller's stream around the selected stages' kernels
