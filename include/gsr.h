@@ -135,10 +135,10 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
  * seven times per frame with different colours (gaussian_renderer/__init__.py:203-272).  The _ex entry points blend
  * n_extra extra colour channels (extra_features[P][n_extra], n_extra == 18 = six RGB triples, each triple composited
  * over `background` like the main colour) in the SAME pass: out_extra[n_extra][H][W]; the backward takes
- * dL_dout_extra[n_extra][H][W] and returns dL_dextra[P][n_extra], every geometric gradient being the sum over all
- * images.  extra_group_mask: bit t set = the image of colour triple t (channels 3t..3t+2) received a gradient; planes of
- * cleared triples are never read (treated as zero) and cost no work -- a training loss typically touches two or three of
- * the six feature images (train.py:256-286).  With extra_features == NULL / n_extra == 0 the _ex entry points are
+ * dL_dout_extra = HOST array of n_extra / 3 device pointers, one [3][H][W] gradient image per colour triple, and returns
+ * dL_dextra[P][n_extra], every geometric gradient being the sum over all images.  A null entry = that image received no
+ * gradient: it is treated as zero and costs no work -- a training loss typically touches two or three of the six feature
+ * images (train.py:256-286).  With extra_features == NULL / n_extra == 0 the _ex entry points are
  * identical to the plain ones. */
 int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
                              gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
@@ -164,7 +164,7 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
                               const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
                               float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                               float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
-                              const float *dL_dout_extra, unsigned extra_group_mask, float *dL_dextra, gsr_stream_t stream);
+                              const float *const *dL_dout_extra, float *dL_dextra, gsr_stream_t stream);
 
 /* Fused gradient of L = mean|color - gt| + lambda_alpha * mean (alpha - mask)^2 (train.py:261-262 with the masks set to
  * the whole image): dL_dcolor[3][H][W] = sign(color - gt) / (3 H W), dL_dalpha[H][W] = 2 lambda (alpha - mask) / (H W). */

@@ -74,7 +74,7 @@ def _load():
     lib.gsr_alpha_mask_loss_backward.restype = C.c_int
     lib.gsr_rasterize_forward_ex.argtypes = lib.gsr_rasterize_forward.argtypes[:-1] + [fp, C.c_int, fp, vp]
     lib.gsr_rasterize_forward_async_ex.argtypes = lib.gsr_rasterize_forward_async.argtypes[:-1] + [fp, C.c_int, fp, vp]
-    lib.gsr_rasterize_backward_ex.argtypes = lib.gsr_rasterize_backward.argtypes[:-1] + [fp, C.c_int, fp, C.c_uint, fp, vp]
+    lib.gsr_rasterize_backward_ex.argtypes = lib.gsr_rasterize_backward.argtypes[:-1] + [fp, C.c_int, C.POINTER(C.c_void_p), fp, vp]
     for _n in ("gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex"):
         getattr(lib, _n).restype = C.c_int
     lib.gsr_query_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]

@@ -84,7 +84,6 @@ __device__ __forceinline__ void normalize_bwd(const float *n, float len, const f
 __device__ __forceinline__ void argsort3(const float s[3], int idx[3]) {
   const int r0 = (s[1] < s[0]) + (s[2] < s[0]);
   const int r1 = (s[0] <= s[1]) + (s[2] < s[1]);
-  const int r2 = (s[0] <= s[2]) + (s[1] <= s[2]);
   // idx[m] = the element whose rank is m (written without dynamic indexing: that would put the array in scratch)
 #pragma unroll
   for (int m = 0; m < 3; m++) idx[m] = r0 == m ? 0 : (r1 == m ? 1 : 2);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       for (int c = 0; c < CE; c++) {
         // colour triples whose image received no gradient (mask bit clear) are never read and cost nothing below
         const bool on = (a.extra_mask >> (c / 3)) & 1u;
-        dxp[c] = (on && inside) ? a.dL_dextra_pix[(size_t)c * plane + p] : 0.f;
+        dxp[c] = (on && inside) ? a.dL_dextra_tri[c / 3][(size_t)(c % 3) * plane + p] : 0.f;
         bgd += (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2)) * dxp[c];
       }
     }
@@ -396,7 +396,7 @@ int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
   if (a.CE != 0) {
-    if (a.CE != CE_MAX || !a.extra || !a.dL_dextra_pix) {
+    if (a.CE != CE_MAX || !a.extra) {
       set_error("fused feature blend backward: exactly %d extra channels with their arrays are required", CE_MAX);
       return GSR_EINVAL;
     }

@@ -447,7 +447,7 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
                               const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
                               float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                               float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
-                              const float *dL_dout_extra, unsigned extra_group_mask, float *dL_dextra, gsr_stream_t stream_) {
+                              const float *const *dL_dout_extra, float *dL_dextra, gsr_stream_t stream_) {
   (void)alphas;  // unused by the reference kernel as well (CR/backward.cu:410)
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (P < 0 || R < 0 || width <= 0 || height <= 0) {
@@ -496,8 +496,11 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   ba.grad_rows = geom.grad_rows;
   ba.extra = extra_features;
   ba.CE = n_extra;
-  ba.dL_dextra_pix = dL_dout_extra;
-  ba.extra_mask = n_extra ? (extra_group_mask & ((1u << (CE_MAX / 3)) - 1u)) : 0u;
+  ba.extra_mask = 0u;
+  for (int t = 0; t < CE_MAX / 3; t++) {
+    ba.dL_dextra_tri[t] = (n_extra && dL_dout_extra) ? dL_dout_extra[t] : nullptr;
+    if (ba.dL_dextra_tri[t]) ba.extra_mask |= 1u << t;
+  }
   prof_begin(PROF_BLEND_BWD, stream);
   int rc = launch_blend_backward(ba, stream);
   prof_end(PROF_BLEND_BWD, stream);
@@ -560,7 +563,7 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
                                    scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
                                    radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D,
                                    dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug,
-                                   nullptr, 0, nullptr, 0u, nullptr, stream);
+                                   nullptr, 0, nullptr, nullptr, stream);
 }
 
 int gsr_query_state(int what, int P, int R, int width, int height, const char *geom_buffer, const char *binning_buffer,

@@ -197,7 +197,7 @@ struct BlendBwdArgs {
   float *grad_rows;  // [P][GROW] (CE == 0) or [P][GROWX] (CE > 0), zeroed
   const float *extra;          // [P][CE]
   int CE;
-  const float *dL_dextra_pix;  // [CE][H][W]
+  const float *dL_dextra_tri[CE_MAX / 3];  // per colour triple: [3][H][W] gradient image, null = no gradient
   uint32_t extra_mask;         // bit t: colour triple t (channels 3t..3t+2) has an incoming gradient
 };
 int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream);

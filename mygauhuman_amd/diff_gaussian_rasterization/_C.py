@@ -93,14 +93,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,
-                                 debug, out=None, extra=None, dL_dout_extra=None, extra_group_mask=0x3F):
+                                 debug, out=None, extra=None, dL_dout_extra=None):
     """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207).
 
     `out` (extension, keyword only in practice): dict name -> preallocated contiguous float32 tensor for any of
     means3D / sh / opacity / scales / rotations / cov3D / colors / means2D; the view-parallel trainer passes views of
     one flat all-reduce bucket so gradients are produced in place.
-    `extra`, `dL_dout_extra` [18,H,W], `extra_group_mask` (extension): the fused multi-feature blend; bit t of the mask
-    says that colour triple t has a gradient (planes of the other triples are not read)."""
+    `extra` [P,18], `dL_dout_extra` (extension): the fused multi-feature blend; dL_dout_extra is a list of six [3,H,W]
+    gradient images (None = that image received no gradient and costs nothing), or one [18,H,W] tensor."""
     dev = means3D.device
     P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
@@ -129,7 +129,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_drotations = _get("rotations", (P, 4), new if has_sr else torch.zeros)
     dL_dextra = None
     if extra is not None:
-        extra, dL_dout_extra = _f32c(extra, "extra"), _f32c(dL_dout_extra, "dL_dout_extra")
+        extra = _f32c(extra, "extra")
+        if isinstance(dL_dout_extra, torch.Tensor):
+            dL_dout_extra = [dL_dout_extra[3 * t:3 * t + 3] for t in range(_lib.N_EXTRA // 3)]
+        grads_extra = [None if g is None else _f32c(g, "dL_dout_extra") for g in dL_dout_extra]   # kept alive until the launch
+        extra_ptrs = (C.c_void_p * (_lib.N_EXTRA // 3))(*[None if g is None else g.data_ptr() for g in grads_extra])
         dL_dextra = new((P, _lib.N_EXTRA), **opts)
     if P != 0:
         means3D, colors = _f32c(means3D, "means3D"), _f32c(colors, "colors")
@@ -148,7 +152,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 ptr(dL_dout_alpha), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
-                ptr(extra), 0 if extra is None else _lib.N_EXTRA, ptr(dL_dout_extra), int(extra_group_mask) & 0x3F,
+                ptr(extra), 0 if extra is None else _lib.N_EXTRA, None if extra is None else extra_ptrs,
                 None if dL_dextra is None else dL_dextra.data_ptr(), _stream(dev))
         check(rc, "gsr_rasterize_backward")
     if extra is not None:

@@ -115,12 +115,6 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha,
          extra) = ctx.saved_tensors
         H, W = alpha.shape[-2], alpha.shape[-1]
-        grad_extra = torch.empty((N_EXTRA, H, W), dtype=torch.float32, device=alpha.device)
-        mask = 0
-        for i, g in enumerate(grad_feats):
-            if g is not None:
-                grad_extra[3 * i:3 * i + 3].copy_(g)
-                mask |= 1 << i
         grad_out_color = torch.zeros((3, H, W), dtype=torch.float32, device=alpha.device) if grad_out_color is None else grad_out_color
         grad_depth = torch.zeros_like(alpha) if grad_depth is None else grad_depth
         grad_alpha = torch.zeros_like(alpha) if grad_alpha is None else grad_alpha
@@ -128,8 +122,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
          grad_rotations, grad_extra_in) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
-            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, extra=extra, dL_dout_extra=grad_extra,
-            extra_group_mask=mask)
+            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, extra=extra, dL_dout_extra=list(grad_feats))
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_extra_in, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, None)
 
