@@ -105,6 +105,22 @@ def cpu_baseline(wl, cam, g, gt, mask, bg):
 PMC_KERNEL = {"blend_bwd": "blend_backward_kernel<1, 0, 0>", "blend_fwd": "blend_forward_kernel<1, 0>"}
 
 
+def measured_copy_gbs(dev):
+    """Stream-copy ceiling of this GPU (read + write bytes per second of a 1 GiB device-to-device copy), SURVEY.md §8(d)."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def pmc_traffic(stage, workload):
     """Memory-side bytes per launch of the dominant kernel.  PMC passes cannot run inside the bench, so the figure comes from
     the newest committed summary profiles/*_pmc.csv (tools/profile_round.sh: separate rocprofv3 --pmc passes of THIS command
@@ -245,6 +261,7 @@ def main():
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items() if k in sb},
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_hbm_frac": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 5),
+            "hbm_copy_measured_gbs": measured_copy_gbs(dev),
         }
         if not a.no_cpu_baseline:
             cam0 = cameras.make_camera(W, H, 50.0) if world == 1 else cam
