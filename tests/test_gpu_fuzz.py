@@ -1,0 +1,45 @@
+"""Randomised parity sweep with the library defaults (tile-bucket binning, tight tile culling, separable backward): image sizes,
+Gaussian counts, scales, SH degrees, culled fractions and both input modes drawn from a seeded generator; images and every
+gradient against the CPU oracle at 1e-4, radii bit-exact, tile lists sublists of the oracle's."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(9, 200)), int(rng.integers(9, 160))
+    P = int(rng.choice([1, 7, 300, 2000, 6000]))
+    deg = int(rng.integers(0, 4))
+    scale = float(rng.choice([0.004, 0.02, 0.08, 0.3]))
+    behind = float(rng.choice([0.0, 0.1, 0.5]))
+    mode = "sh" if rng.uniform() < 0.5 else "precomp"
+    return P, W, H, deg, scale, behind, mode
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_forward_backward(oracle, seed):
+    P, W, H, deg, scale, behind, mode = _draw(seed)
+    cam, g = util.make_scene(P, W, H, seed, deg, scale, behind)
+    bg = np.random.default_rng(seed).uniform(0, 1, 3).astype(np.float32)
+    ref = util.oracle_forward(oracle, cam, g, bg, mode)
+    f = util.hip_forward(cam, g, bg, mode)
+    np.testing.assert_array_equal(f["radii"].cpu().numpy(), ref["pre"]["radii"])
+    assert f["R"] == ref["bin"]["R"]
+    util.assert_lists_are_sublists(f, ref["bin"], ((W + 15) // 16) * ((H + 15) // 16))
+    solid = ref["img"]["fragile"] == 0
+    for k in ("color", "depth", "alpha"):
+        m = np.broadcast_to(solid, ref["img"][k].shape)
+        util.assert_close(k, f[k].cpu().numpy(), ref["img"][k], mask=m, max_bad_frac=1e-4)
+    rng = np.random.default_rng(seed + 50)
+    dc = (rng.normal(0, 1, (3, H, W)) * solid).astype(np.float32)
+    dd = (rng.normal(0, 1, (1, H, W)) * solid).astype(np.float32)
+    da = (rng.normal(0, 1, (1, H, W)) * solid).astype(np.float32)
+    want = oracle.rasterize_backward(ref, dc, dd, da)
+    got = util.hip_backward(f, dc, dd, da)
+    names = ["dL_dmean2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D"] + (["dL_dsh", "dL_dscales", "dL_drotations"] if mode == "sh" else [])
+    for n in names:
+        util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=3e-4)
