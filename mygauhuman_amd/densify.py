@@ -145,9 +145,18 @@ def training_setup(model, lrs, percent_dense=0.01):
 
 
 def add_densification_stats(model, viewspace_point_tensor, update_filter):
+    """scene/gaussian_model.py:764-766.  Same values, written without boolean-mask indexing (which costs a nonzero kernel and
+    a host synchronisation per statement): rows outside the filter get + 0."""
     g = viewspace_point_tensor.grad if viewspace_point_tensor.grad is not None else viewspace_point_tensor
-    model.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
-    model.denom[update_filter] += 1
+    f = update_filter.to(model.denom.dtype).unsqueeze(-1)
+    model.xyz_gradient_accum += torch.norm(g[:, :2], dim=-1, keepdim=True) * f
+    model.denom += f
+
+
+def update_max_radii(model, radii, visibility_filter):
+    """max_radii2D[vis] = max(max_radii2D[vis], radii[vis]) (train.py:403) without the boolean-mask gather / scatter."""
+    r = radii.to(model.max_radii2D.dtype)
+    model.max_radii2D = torch.where(visibility_filter, torch.maximum(model.max_radii2D, r), model.max_radii2D)
 
 
 def prune_points(model, mask):
