@@ -140,7 +140,9 @@ def training_setup(model, lrs, percent_dense=0.01):
     model.denom = torch.zeros((P, 1), device=dev)
     model.max_radii2D = torch.zeros((P,), device=dev)
     groups = [{"params": [getattr(model, ATTR[g])], "lr": float(lrs.get(g, 0.0)), "name": g} for g in GROUPS]
-    model.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    # same update rule as the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15) (:283); on the GPU the fused implementation
+    # runs one kernel per group instead of the foreach path's ~8
+    model.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=True if dev.type == "cuda" else None)
     return model.optimizer
 
 

@@ -22,7 +22,7 @@ def to_model(st, with_adam=True):
     if with_adam:
         for g in densify.GROUPS:
             p = getattr(m, densify.ATTR[g])
-            m.optimizer.state[p] = dict(step=torch.tensor(3.0), exp_avg=torch.from_numpy(st["exp_avg"][g]).cuda(),
+            m.optimizer.state[p] = dict(step=torch.tensor(3.0, device="cuda"), exp_avg=torch.from_numpy(st["exp_avg"][g]).cuda(),
                                         exp_avg_sq=torch.from_numpy(st["exp_avg_sq"][g]).cuda())
     m.xyz_gradient_accum = torch.from_numpy(st["xyz_gradient_accum"]).cuda()
     m.denom = torch.from_numpy(st["denom"]).cuda()
