@@ -42,7 +42,8 @@ def _hipcc():
 def build(force=False, verbose=False, save_temps=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "gsr_common.h"), os.path.join(HERE, "..", "include", "gsr.h"), os.path.abspath(__file__)]
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(HERE, "..", "include", "gsr.h"),
+                                                                                       os.path.abspath(__file__)]
     hdr_m = max(os.path.getmtime(h) for h in hdrs)
     objs, rebuilt = [], False
     procs = []
