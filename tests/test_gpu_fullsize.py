@@ -116,3 +116,43 @@ def test_c3_forward_backward_properties():
         assert not np.any(v.reshape(P, -1)[invisible]), k
     _lib.set_tuning("blend_fwd_waves", 4)
     _lib.set_tuning("blend_bwd_waves", 4)
+
+
+def test_c5_lbs_render_prune_at_500k(oracle):
+    """BASELINE configs[4] at full size (fp32 SH): 500k articulated Gaussians -> per-frame LBS + fused render() forward / backward
+    at 1024^2 -> k-NN based prune.  Size-independent properties: finite outputs, visible <=> radii > 0, gradients only on
+    visible Gaussians, nearest-vertex distances equal to the brute-force oracle's, prune count equal to the mask count."""
+    import types
+
+    from mygauhuman_amd import densify, knn_cuda
+    from mygauhuman_amd.gaussian_renderer import render
+    from tools.train_demo import build
+    P, V, W, H = 500_000, 6890, 1024, 1024
+    model, cam, verts = build(P, V, W, H, seed=5)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    o = render(1, cam, model, pipe, torch.zeros(3, device="cuda"))
+    assert o["render"].shape == (3, H, W) and o["normal"].shape == (3, H, W)
+    for k in ("render", "render_alpha", "render_depth", "normal", "albedo", "render_axis"):
+        assert torch.isfinite(o[k]).all(), k
+    amax = float(o["render_alpha"].detach().max())
+    assert 0.9 < amax <= 1.0 + 1e-4
+    loss = o["render"].mean() + o["render_alpha"].mean() + o["normal"].mean() + o["render_axis"].mean()
+    loss.backward()
+    vis = o["visibility_filter"]
+    assert int(vis.sum()) > 0.9 * P
+    for p in (model._xyz, model._features_dc, model._scaling, model._rotation, model._opacity, model._normal):
+        assert torch.isfinite(p.grad).all()
+    assert float(model._features_dc.grad[~vis].abs().sum()) == 0.0 and float(model._opacity.grad[~vis].abs().sum()) == 0.0
+    assert float(model._features_dc.grad[vis].abs().sum()) > 0.0
+    # distance of every Gaussian to the SMPL surface (the prune prior, scene/gaussian_model.py:715-720) against brute force
+    dist, idx = knn_cuda.knn_nearest(verts, model._xyz.detach())
+    sub = np.random.default_rng(0).choice(P, 20000, replace=False)
+    q = model._xyz.detach()[torch.from_numpy(sub).cuda()].cpu().numpy()
+    ids = oracle.nearest_vertex(q, verts.cpu().numpy())
+    np.testing.assert_array_equal(idx.cpu().numpy()[sub], ids)
+    np.testing.assert_allclose(dist.cpu().numpy()[sub], oracle.nearest_dist(q, verts.cpu().numpy(), ids), rtol=2e-7)
+    densify.training_setup(model, dict(xyz=1e-4))
+    model._xyz.data[:1000] += 1.0                       # push 1000 Gaussians away from the body: they must be pruned
+    mask = densify.densify_and_prune(model, 1e9, 0.0, 2.0, 0, t_vertices=verts)
+    assert int(mask[:1000].sum()) == 1000
+    assert model._xyz.shape[0] == P - int(mask.sum()) and model._features_rest.shape == (model._xyz.shape[0], 15, 3)
