@@ -240,13 +240,17 @@ int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals,
  * belong to the constant big pose / shape and get no gradient in the reference training loop).
  * Incoming: dL_dworld_pts[P][3], dL_dtransforms[P][9], dL_dworld_normals[P][3] (each may be null = zero).
  * Outgoing (zero-filled by the caller, accumulated into): dL_dquery[P][3], dL_dnormals[P][3] (or null),
- *   dL_dlbs_offsets[P][24] (or null), dL_dA_pose[24][16], dL_doff_pose[V][3]. */
+ *   dL_dlbs_offsets[P][24] (or null), dL_dA_pose[24][16] (or null), dL_doff_pose[V][3] (or null).
+ * dA_pose_partials (optional): [gsr_lbs_backward_workgroups(P)][24 * 12] floats.  When given (and dL_dA_pose is non-null)
+ *   every workgroup stores its own sum there instead of issuing 288 atomics onto dL_dA_pose; the caller adds the rows up
+ *   (entry j * 12 + k belongs to dL_dA_pose[j][k / 4][k % 4]) -- dL_dA_pose itself is then left untouched. */
+int gsr_lbs_backward_workgroups(int P);
 int gsr_lbs_backward(int P, int V, const float *query, const float *normals, const int *vert_ids,
                      const float *weights, const float *lbs_offsets, const float *A_big, const float *A_pose,
                      const float *off_big, const float *off_shape, const float *off_pose, const float *R,
                      const float *dL_dworld_pts, const float *dL_dtransforms, const float *dL_dworld_normals,
                      float *dL_dquery, float *dL_dnormals, float *dL_dlbs_offsets, float *dL_dA_pose,
-                     float *dL_doff_pose, gsr_stream_t stream);
+                     float *dL_doff_pose, float *dA_pose_partials, gsr_stream_t stream);
 
 /* Fused SSIM (extension): utils/loss_utils.py:25-66 -- 11x11 Gaussian window (sigma 1.5), zero
  * padding, C1 = 0.01^2, C2 = 0.03^2 -- over `planes` independent H x W planes (batch x channels of the reference's grouped

@@ -406,6 +406,7 @@ struct LbsBwdArgs {
   const int *vert_ids;
   const float *dL_dworld_pts, *dL_dtransforms, *dL_dworld_normals;
   float *dL_dquery, *dL_dnormals, *dL_dlbs_offsets, *dL_dA_pose, *dL_doff_pose;
+  float *partials;  // [workgroups][24 * 12] per-workgroup dA_pose sums (no atomics) or null
 };
 
 __global__ __launch_bounds__(LBS_BLOCK) void lbs_backward_kernel(const LbsBwdArgs a) {
@@ -551,7 +552,10 @@ __global__ __launch_bounds__(LBS_BLOCK) void lbs_backward_kernel(const LbsBwdArg
       const int j = e / 12, k = e % 12;
       float acc = 0.f;
       for (int q = 0; q < LBS_BLOCK; q++) acc += s_rows[q * ROW + j] * s_rows[q * ROW + NJ + k];
-      if (acc != 0.f) atomicAdd(&a.dL_dA_pose[16 * j + k], acc);
+      if (a.partials)
+        a.partials[(size_t)blockIdx.x * (NJ * 12) + e] = acc;  // reduced by the caller: 782 workgroups x 288 atomics onto the
+      else if (acc != 0.f)                                       // same 288 addresses serialise at the memory side
+        atomicAdd(&a.dL_dA_pose[16 * j + k], acc);
     }
 }
 
@@ -578,6 +582,8 @@ int gsr_lbs_forward(int P, int V, const float *query, const float *normals, cons
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
 }
+
+int gsr_lbs_backward_workgroups(int P) { return P > 0 ? (P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK : 0; }
 
 size_t gsr_lbs_workspace_bytes(int V) { return V > 0 ? gsr::grid_workspace_bytes(V) : 0; }
 
@@ -643,7 +649,8 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
                      const float *lbs_offsets, const float *A_big, const float *A_pose, const float *off_big,
                      const float *off_shape, const float *off_pose, const float *R, const float *dL_dworld_pts,
                      const float *dL_dtransforms, const float *dL_dworld_normals, float *dL_dquery, float *dL_dnormals,
-                     float *dL_dlbs_offsets, float *dL_dA_pose, float *dL_doff_pose, gsr_stream_t stream_) {
+                     float *dL_dlbs_offsets, float *dL_dA_pose, float *dL_doff_pose, float *dA_pose_partials,
+                     gsr_stream_t stream_) {
   if (P < 0 || V <= 0 || (P > 0 && (!query || !vert_ids || !weights || !A_big || !A_pose || !off_big || !off_shape ||
                                     !off_pose || !R || !dL_dquery))) {
     gsr::set_error("gsr_lbs_backward: bad arguments");
@@ -653,7 +660,7 @@ int gsr_lbs_backward(int P, int V, const float *query, const float *normals, con
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   gsr::LbsBwdArgs a = {P, V, query, normals, weights, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, vert_ids,
                        dL_dworld_pts, dL_dtransforms, dL_dworld_normals, dL_dquery, dL_dnormals, dL_dlbs_offsets, dL_dA_pose,
-                       dL_doff_pose};
+                       dL_doff_pose, dL_dA_pose ? dA_pose_partials : nullptr};
   hipLaunchKernelGGL(gsr::lbs_backward_kernel, dim3((P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK), dim3(gsr::LBS_BLOCK), 0, stream, a);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;

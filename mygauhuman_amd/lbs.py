@@ -270,12 +270,15 @@ class _LBSDeform(torch.autograd.Function):
         # of every workgroup onto 288 + 3V addresses
         need_A, need_off = ctx.needs_input_grad[4], ctx.needs_input_grad[7]
         d_A = torch.zeros((24, 16), dtype=f32, device=dev) if need_A else None
+        partials = torch.empty((lib.gsr_lbs_backward_workgroups(P), 24 * 12), dtype=f32, device=dev) if need_A else None
         d_off = torch.zeros((V, 3), dtype=f32, device=dev) if need_off else None
         with torch.cuda.device(dev):
             check(lib.gsr_lbs_backward(P, V, ptr(query), ptr(normals), ptr(vert_ids), ptr(w), ptr(loff), ptr(A_big), ptr(A_pose),
                                        ptr(ob), ptr(os_), ptr(op), ptr(R), ptr(g_world), ptr(g_transforms), ptr(g_normals),
-                                       ptr(d_query), ptr(d_normals), ptr(d_loff), ptr(d_A), ptr(d_off),
+                                       ptr(d_query), ptr(d_normals), ptr(d_loff), ptr(d_A), ptr(d_off), ptr(partials),
                                        torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_backward")
+        if need_A:  # per-workgroup sums -> rows 0..2 of the 24 4x4 gradients (row 3 of A is constant)
+            d_A.view(24, 4, 4)[:, :3, :] = partials.sum(0).view(24, 3, 4)
         return (d_query, d_normals, d_loff, None, None if d_A is None else d_A.view(A_shape), None, None,
                 None if d_off is None else d_off.view(off_shape_), None, None, None, None, None)
 
