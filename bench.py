@@ -263,9 +263,8 @@ def main():
             "frame_hbm_frac": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 5),
             "hbm_copy_measured_gbs": measured_copy_gbs(dev),
         }
-        if not a.no_cpu_baseline:
-            cam0 = cameras.make_camera(W, H, 50.0) if world == 1 else cam
-            out["cpu_baseline"] = cpu_baseline(wl, cam0, g, gt, mask, bg_np)
+        if not a.no_cpu_baseline and world == 1:  # the CPU baseline is reported by the 1-GPU run only
+            out["cpu_baseline"] = cpu_baseline(wl, cameras.make_camera(W, H, 50.0), g, gt, mask, bg_np)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
