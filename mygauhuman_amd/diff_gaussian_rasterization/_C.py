@@ -90,6 +90,119 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return rendered.value, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor
 
 
+class AsyncCapacity:
+    """Capacity policy and deferred overflow checks of the sync-free forward (rasterize_gaussians_async).
+
+    The blocking read of num_rendered (CR/rasterizer_impl.cu:283) exists to size the binning buffer.  On a 288 GB part the
+    buffer is simply sized generously instead -- max(MIN, 64 instances per Gaussian, 2 x the largest R seen so far), 24 B per
+    instance -- and the device reports R and an overflow flag into `status`.  The flag travels to pinned host memory with an
+    asynchronous copy; it is examined when the frame's backward starts, at the next forward, or by check_all(): an overflow
+    raises RuntimeError there (the overflowing frame rendered only the background) and the capacity is raised for the retry."""
+    MIN = 4 << 20
+    largest_R = 0
+    pending = []
+    _pinned = []  # recycled 2-int pinned host tensors (hipHostMalloc per frame would cost more than the read it replaces)
+
+    @classmethod
+    def capacity(cls, P):
+        return int(max(cls.MIN, 64 * P, 2 * cls.largest_R))
+
+    @classmethod
+    def watch(cls, status, capacity):
+        host = cls._pinned.pop() if cls._pinned else torch.empty(2, dtype=torch.int32).pin_memory()
+        host.copy_(status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(status.device))
+        w = [host, ev, int(capacity), False]
+        cls.pending.append(w)
+        return w
+
+    @classmethod
+    def _examine(cls, w, wait):
+        if w[3]:
+            return
+        if wait:
+            w[1].synchronize()
+        elif not w[1].query():
+            return
+        w[3] = True
+        if w in cls.pending:
+            cls.pending.remove(w)
+        R, overflow = int(w[0][0]) & 0xFFFFFFFF, int(w[0][1]) != 0
+        cls._pinned.append(w[0])
+        cls.largest_R = max(cls.largest_R, R)
+        if overflow:
+            raise RuntimeError(f"rasterize_gaussians_async: {R} (Gaussian, tile) instances exceeded the binning capacity of {w[2]}; "
+                               "that frame rendered only the background.  The capacity has been raised: render it again.")
+
+    @classmethod
+    def poll(cls):
+        for w in list(cls.pending):
+            cls._examine(w, wait=False)
+
+    @classmethod
+    def check(cls, w):
+        cls._examine(w, wait=True)
+
+    @classmethod
+    def check_all(cls):
+        for w in list(cls.pending):
+            cls._examine(w, wait=True)
+
+
+def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                              projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+                              debug, extra=None, capacity=None):
+    """Sync-free forward (extension): same inputs as rasterize_gaussians, no host read of num_rendered.
+    Returns (capacity, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra | None, watch) where
+    `capacity` takes the place of num_rendered in rasterize_gaussians_backward and `watch` is the deferred overflow check
+    (AsyncCapacity.check(watch))."""
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("rasterize_gaussians_async: tensors must live on a HIP device (no CPU path)")
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    if P == 0:
+        out = rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                  projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+                                  debug, extra=extra)
+        return (0,) + tuple(out[1:8]) + ((out[8] if extra is not None else None), None)
+    AsyncCapacity.poll()
+    cap = int(capacity) if capacity is not None else AsyncCapacity.capacity(P)
+    f32, u8 = torch.float32, torch.uint8
+    out_color = torch.empty((3, H, W), dtype=f32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=f32, device=dev)
+    out_alpha = torch.empty((1, H, W), dtype=f32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty((lib.gsr_geometry_bytes(P),), dtype=u8, device=dev)
+    img = torch.empty((lib.gsr_image_bytes(W, H),), dtype=u8, device=dev)
+    binning = torch.empty((lib.gsr_binning_bytes(cap, W, H),), dtype=u8, device=dev)
+    status = torch.empty((2,), dtype=torch.int32, device=dev)
+    out_extra = None
+    if extra is not None:
+        if tuple(extra.shape) != (P, _lib.N_EXTRA):
+            raise RuntimeError(f"extra must have shape (num_points, {_lib.N_EXTRA})")
+        extra = _f32c(extra, "extra")
+        out_extra = torch.empty((_lib.N_EXTRA, H, W), dtype=f32, device=dev)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    means3D, colors, opacity = _f32c(means3D, "means3D"), _f32c(colors, "colors"), _f32c(opacity, "opacity")
+    scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
+    sh, background = _f32c(sh, "sh"), _f32c(background, "background")
+    viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
+    with torch.cuda.device(dev):
+        rc = lib.gsr_rasterize_forward_async_ex(
+            geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, int(degree), int(M), ptr(background), W, H, ptr(means3D),
+            ptr(sh), ptr(colors), ptr(opacity), ptr(scales), float(scale_modifier), ptr(rotations), ptr(cov3D_precomp),
+            ptr(viewmatrix), ptr(projmatrix), ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+            out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr(), int(bool(debug)),
+            status.data_ptr(), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
+            None if out_extra is None else out_extra.data_ptr(), _stream(dev))
+        check(rc, "gsr_rasterize_forward_async")
+        watch = AsyncCapacity.watch(status, cap)
+    return cap, out_color, out_depth, out_alpha, radii, geom, binning, img, out_extra, watch
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,

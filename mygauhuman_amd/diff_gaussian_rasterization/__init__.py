@@ -94,11 +94,19 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
     channels instead of seven rasterizer calls with identical geometry (gaussian_renderer/__init__.py:203-272)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                sync_free=False):
         rs = raster_settings
-        out = _C.rasterize_gaussians(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
-                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
-                                     rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, extra=extra)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
+                rs.debug)
+        ctx.watch = None
+        if sync_free:  # no host read of num_rendered: generous capacity + deferred overflow check (_C.AsyncCapacity)
+            out = _C.rasterize_gaussians_async(*args, extra=extra)
+            ctx.watch = out[9]
+            out = out[:9]
+        else:
+            out = _C.rasterize_gaussians(*args, extra=extra)
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra = out
         ctx.set_materialize_grads(False)  # untouched images arrive as None in backward, not as zero tensors
         ctx.raster_settings = rs
@@ -112,6 +120,8 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha, *grad_feats):
         rs = ctx.raster_settings
+        if ctx.watch is not None:
+            _C.AsyncCapacity.poll()  # non-blocking here: waiting now would keep the backward kernels off the queue
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha,
          extra) = ctx.saved_tensors
         H, W = alpha.shape[-2], alpha.shape[-1]
@@ -123,12 +133,16 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
             geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, extra=extra, dL_dout_extra=list(grad_feats))
+        if ctx.watch is not None:
+            # the whole backward is queued; wait for the FORWARD's overflow flag only (the GPU stays busy with the backward)
+            # so that an overflow raises before the optimizer consumes these gradients
+            _C.AsyncCapacity.check(ctx.watch)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_extra_in, grad_opacities, grad_scales,
-                grad_rotations, grad_cov3Ds_precomp, None)
+                grad_rotations, grad_cov3Ds_precomp, None, None)
 
 
 def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors, opacities, scales, rotations, cov3Ds_precomp,
-                              raster_settings):
+                              raster_settings, sync_free=False):
     """Blend the main colour (SHs or colors_precomp) and up to six extra [P,3] colour sets (a list, or one packed [P,18]
     tensor) in one pass.
     Returns (color, radii, depth, alpha, [image_i [3,H,W] for each extra colour set])."""
@@ -144,7 +158,7 @@ def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors
         cols = list(extra_colors) + [torch.zeros((P, 3), dtype=means3D.dtype, device=means3D.device)] * (6 - n)
         extra = torch.cat(cols, dim=1)
     out = _RasterizeGaussiansMulti.apply(means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp,
-                                         raster_settings)
+                                         raster_settings, sync_free)
     return out[0], out[1], out[2], out[3], list(out[4:4 + n])
 
 
@@ -176,9 +190,10 @@ class GaussianRasterizer(nn.Module):
                                    self.raster_settings)
 
     def forward_multi(self, means3D, means2D, opacities, extra_colors, shs=None, colors_precomp=None, scales=None, rotations=None,
-                      cov3D_precomp=None):
+                      cov3D_precomp=None, sync_free=False):
         """Extension: like forward(), plus `extra_colors` (list of 1..6 [P,3] tensors) blended in the same pass.
-        Returns (color, radii, depth, alpha, [extra images])."""
+        Returns (color, radii, depth, alpha, [extra images]).  sync_free=True skips the host read of num_rendered
+        (_C.AsyncCapacity: generous binning capacity, overflow reported at backward / next call)."""
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         has_sr = scales is not None or rotations is not None
@@ -188,4 +203,4 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians_multi(means3D, means2D, empty if shs is None else shs,
                                          empty if colors_precomp is None else colors_precomp, extra_colors, opacities,
                                          empty if scales is None else scales, empty if rotations is None else rotations,
-                                         empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)
+                                         empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, sync_free)

@@ -133,3 +133,45 @@ def test_render_fused_equals_seven_passes(oracle):
     np.testing.assert_array_equal(outs[False]["radii"], outs[True]["radii"])
     for ga, gb in zip(grads[False], grads[True]):
         util.assert_close("render grads", ga, gb, tol=1e-4, max_bad_frac=2e-4)
+
+
+def test_sync_free_forward_multi_equals_blocking_and_reports_overflow(monkeypatch):
+    """sync_free=True (no host read of num_rendered) must give the same images and gradients; an undersized binning capacity
+    must surface as a RuntimeError at backward / at the explicit check, never silently."""
+    from mygauhuman_amd.diff_gaussian_rasterization import GaussianRasterizer, _C
+    P, W, H = 4000, 130, 90
+    cam, g = util.make_scene(P, W, H, 41, 3, 0.03, 0.02)
+    bg = np.array([0.2, 0.5, 0.7], np.float32)
+    rast = GaussianRasterizer(_settings(cam, bg, 3))
+
+    def leaves():
+        rng = np.random.default_rng(8)
+        t = {k: util.to_dev(v).requires_grad_(True) for k, v in g.items() if isinstance(v, np.ndarray)}
+        t["extras"] = [util.to_dev(rng.uniform(0, 1, (P, 3)).astype(np.float32)).requires_grad_(True) for _ in range(6)]
+        t["means2D"] = torch.zeros((P, 3), device="cuda", requires_grad=True)
+        return t
+
+    def run(t, sync_free):
+        out = rast.forward_multi(means3D=t["means3D"], means2D=t["means2D"], opacities=t["opacities"], extra_colors=t["extras"],
+                                 shs=t["shs"], scales=t["scales"], rotations=t["rotations"], sync_free=sync_free)
+        (out[0].sum() + out[3].sum() + out[4][0].sum() + out[4][5].mean()).backward()
+        return out
+
+    a, b = leaves(), leaves()
+    oa, ob = run(a, False), run(b, True)
+    assert torch.equal(oa[1], ob[1])
+    for x, y in zip([oa[0], oa[2], oa[3]] + list(oa[4]), [ob[0], ob[2], ob[3]] + list(ob[4])):
+        assert torch.equal(x, y)
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        util.assert_close(k, b[k].grad.cpu().numpy(), a[k].grad.cpu().numpy(), tol=2e-5, max_bad_frac=1e-4)
+    _C.AsyncCapacity.check_all()
+    assert _C.AsyncCapacity.largest_R > 0 and not _C.AsyncCapacity.pending
+    # undersized capacity: the frame renders only the background and the error is raised at backward
+    monkeypatch.setattr(_C.AsyncCapacity, "capacity", classmethod(lambda cls, n: 64))
+    c = leaves()
+    out = rast.forward_multi(means3D=c["means3D"], means2D=c["means2D"], opacities=c["opacities"], extra_colors=c["extras"],
+                             shs=c["shs"], scales=c["scales"], rotations=c["rotations"], sync_free=True)
+    with pytest.raises(RuntimeError, match="binning capacity"):
+        out[0].sum().backward()
+    assert float((out[0].detach() - util.to_dev(bg)[:, None, None]).abs().max()) == 0.0
+    assert not _C.AsyncCapacity.pending

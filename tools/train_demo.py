@@ -42,13 +42,13 @@ def build(P, V, W, H, seed=0):
 
 
 def main(P=200_000, V=6890, W=1024, H=1024, iters=120):
-    for sep in (False, True):
+    for sep, sync_free in ((False, True), (False, False), (False, True), (False, False), (True, False)):
         torch.manual_seed(0)
         model, cam, verts = build(P, V, W, H)
         densify.training_setup(model, dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=0.05, scaling=5e-3, rotation=1e-3,
                                           normal=1e-3, albedo=0.05, roughness=0.05))
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep,
-                                     torch_attributes=sep)
+                                     torch_attributes=sep, sync_free_raster=sync_free)
         bg = torch.zeros(3, device="cuda")
         gt = torch.rand((3, H, W), device="cuda")
         gt_n = torch.rand((3, H, W), device="cuda")
@@ -84,7 +84,7 @@ def main(P=200_000, V=6890, W=1024, H=1024, iters=120):
             iteration(it)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters * 1e3
-        print(f"training iteration ({'reference structure: seven passes + torch glue + conv2d SSIM' if sep else 'fused path'}), "
+        print(f"training iteration ({'reference structure: seven passes + torch glue + conv2d SSIM' if sep else 'fused path, sync_free_raster=' + str(sync_free)}), "
               f"P={model.get_xyz.shape[0]} after densification, {W}x{H}: {dt:.2f} ms/iteration ({1e3 / dt:.0f} it/s)", flush=True)
 
 
