@@ -113,9 +113,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
   });
 }
 
+// bitonic sorting network over keys[0..npow2) by the whole workgroup, starting at merge level kstart (kstart = 2: a full sort;
+// kstart = 2048: the 1024-key runs are already sorted, even runs ascending and odd runs descending)
 template <typename Ptr>
-__device__ __forceinline__ void bitonic_sort_block(Ptr keys, int npow2) {
-  for (int k = 2; k <= npow2; k <<= 1) {
+__device__ __forceinline__ void bitonic_sort_block(Ptr keys, int npow2, int kstart = 2) {
+  for (int k = kstart; k <= npow2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = threadIdx.x; t < (npow2 >> 1); t += blockDim.x) {
         const int lo = ((t / j) * (j << 1)) + (t % j);
@@ -244,7 +246,25 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
     while (np < n) np <<= 1;
     for (int i = threadIdx.x; i < np; i += blockDim.x) s_keys[i] = i < n ? b[i] : ~0ull;
     __syncthreads();
-    if (np > 1) bitonic_sort_block(s_keys, np);
+    if (np >= 2 * SORT_WAVE_MAX) {
+      // runs of 1024 keys are sorted in REGISTERS by one wave each (no barriers; odd runs descending = ascending sort of the
+      // complemented keys), then only the merge levels k >= 2048 of the network run through LDS: 11..13 barrier stages
+      // instead of 66..91
+      const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+      for (int c = (int)wave; c < np / SORT_WAVE_MAX; c += (int)(blockDim.x / WAVE)) {
+        const uint64_t flip = (c & 1) ? ~0ull : 0ull;
+        uint64_t key[SORT_WAVE_MAX / WAVE];
+#pragma unroll
+        for (int q = 0; q < SORT_WAVE_MAX / WAVE; q++) key[q] = s_keys[c * SORT_WAVE_MAX + q * WAVE + (int)lane] ^ flip;
+        wave_bitonic_sort<SORT_WAVE_MAX / WAVE>(key, lane);
+#pragma unroll
+        for (int q = 0; q < SORT_WAVE_MAX / WAVE; q++) s_keys[c * SORT_WAVE_MAX + q * WAVE + (int)lane] = key[q] ^ flip;
+      }
+      __syncthreads();
+      bitonic_sort_block(s_keys, np, 2 * SORT_WAVE_MAX);
+    } else if (np > 1) {
+      bitonic_sort_block(s_keys, np);
+    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const uint64_t k = s_keys[i];
       point_list[r.x + i] = (uint32_t)k;
@@ -261,6 +281,7 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
       for (int i = threadIdx.x; i < np; i += blockDim.x) s_keys[i] = i < m ? b[c0 + i] : ~0ull;
       __syncthreads();
       bitonic_sort_block(s_keys, np);
+      __syncthreads();
       for (int i = threadIdx.x; i < m; i += blockDim.x) b[c0 + i] = s_keys[i];
       __syncthreads();
     }
@@ -329,6 +350,8 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   GSR_LAUNCH_CHECK(stream, debug);
   hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, stream, ranges, b.keys_a, b.vals_s, b.keys_s);
   GSR_LAUNCH_CHECK(stream, debug);
+  // (a separate 16 KB-LDS instantiation for 1025..2048 keys was measured: slower -- the register sorts of the runs, not the
+  // LDS occupancy, bound this kernel)
   hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)tiles), dim3(256), 0, stream, ranges,
                      b.keys_a, b.vals_s, b.keys_s);
   GSR_LAUNCH_CHECK(stream, debug);
