@@ -144,3 +144,41 @@ def test_render_with_cached_transforms_and_motion_decoders(oracle):
     # same image up to cut-off flips of a few pixels (the cached path recomputes the means as transforms . p + translation)
     d = (cached["render"] - out["render"]).abs().detach().flatten()
     assert float(d.mean()) < 1e-5 and float((d > 2e-4).float().mean()) < 1e-3
+
+
+def test_render_pipe_knobs_agree(oracle):
+    """pipe.torch_attributes (the reference's torch op chain), pipe.sync_free_raster and override_color: same images (to fp32
+    rounding) and gradients as the default path."""
+    from mygauhuman_amd.gaussian_renderer import render
+    s = _human_scene(oracle)
+    bg = util.to_dev(np.array([0.3, 0.1, 0.2], np.float32))
+    keys = ("render", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis", "render_alpha", "render_depth")
+
+    def run(**kw):
+        for p in s.model.parameters():
+            p.grad = None
+        extra = {k: kw.pop(k) for k in ("override_color",) if k in kw}
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, **kw)
+        o = render(1, s.cam, s.model, pipe, bg, **extra)
+        sum(o[k].mean() for k in keys).backward()
+        return {k: o[k].detach().clone() for k in keys}, [None if p.grad is None else p.grad.detach().clone() for p in s.model.parameters()]
+
+    base, gbase = run()
+    for variant in (dict(torch_attributes=True), dict(sync_free_raster=True)):
+        out, grads = run(**variant)
+        for k in keys:
+            d = (out[k] - base[k]).abs()
+            assert float(d.mean()) < 2e-5 and float((d > 2e-3).float().mean()) < 1e-3, (variant, k, float(d.max()))
+        for ga, gb in zip(grads, gbase):
+            if gb is None:
+                assert ga is None
+                continue
+            scale = float(gb.abs().max()) + 1e-12
+            assert float((ga - gb).abs().mean()) / scale < 1e-4, variant
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    _C.AsyncCapacity.check_all()
+    col = torch.rand((s.g["means3D"].shape[0], 3), device="cuda")
+    out, grads = run(override_color=col)
+    assert float((out["render"] - base["render"]).abs().max()) > 1e-3            # different colours ...
+    assert float((out["normal"] - base["normal"]).abs().max()) < 1e-5             # ... same geometry and feature images
+    assert grads[1] is None or float(grads[1].abs().sum()) == 0.0                  # SH coefficients unused
