@@ -105,6 +105,23 @@ def cpu_baseline(wl, cam, g, gt, mask, bg):
 PMC_KERNEL = {"blend_bwd": "blend_backward_kernel<1, 0, 0>", "blend_fwd": "blend_forward_kernel<1, 0>"}
 
 
+def list_stats(session, P, W, H):
+    """Per-tile list statistics of the last frame: instances kept after the exact tile culling, mean list
+    length over non-empty tiles, fraction of pixels whose blend stopped early (transmittance cut-off before the end of the list)."""
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    q = lambda what: _C.query_state(what, P, session.capacity, W, H, session.geom, session.bin, session.img)  # noqa: E731
+    ranges = q("RANGES").long()
+    lens = ranges[:, 1] - ranges[:, 0]
+    gx = (W + 15) // 16
+    ncon, T = q("N_CONTRIB").long(), q("FINAL_T")
+    ys, xs = torch.meshgrid(torch.arange(H, device=T.device), torch.arange(W, device=T.device), indexing="ij")
+    tile_len = lens[(ys // 16) * gx + xs // 16]
+    early = (ncon < tile_len) & (T < 1e-3)
+    ne = lens > 0
+    return {"instances_after_tile_cull": int(lens.sum()), "mean_list_length": round(float(lens[ne].float().mean()), 1) if bool(ne.any()) else 0.0,
+            "max_list_length": int(lens.max()), "pixels_stopped_early_frac": round(float(early.float().mean()), 4)}
+
+
 def measured_copy_gbs(dev):
     """Stream-copy ceiling of this GPU (read + write bytes per second of a 1 GiB device-to-device copy), SURVEY.md §8(d)."""
     n = 1 << 28
@@ -262,6 +279,7 @@ def main():
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_hbm_frac": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 5),
             "hbm_copy_measured_gbs": measured_copy_gbs(dev),
+            "list_stats": list_stats(step.session if step is not None else fsession, P, W, H),
         }
         if not a.no_cpu_baseline and world == 1:  # the CPU baseline is reported by the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(wl, cameras.make_camera(W, H, 50.0), g, gt, mask, bg_np)
