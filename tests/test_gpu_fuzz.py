@@ -20,7 +20,12 @@ def _draw(seed):
     return P, W, H, deg, scale, behind, mode
 
 
-@pytest.mark.parametrize("seed", range(24))
+import os  # noqa: E402
+
+N_SEEDS = int(os.environ.get("GSR_FUZZ_SEEDS", "24"))  # GSR_FUZZ_SEEDS=200 for a long sweep
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_scene_forward_backward(oracle, seed):
     P, W, H, deg, scale, behind, mode = _draw(seed)
     cam, g = util.make_scene(P, W, H, seed, deg, scale, behind)
