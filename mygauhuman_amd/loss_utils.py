@@ -22,32 +22,26 @@ def l2_loss(network_output, gt):
     return ((network_output - gt) ** 2).mean()
 
 
-def gaussian(window_size, sigma):
-    gauss = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
-    return gauss / gauss.sum()
-
-
-def create_window(window_size, channel):
-    _1D_window = gaussian(window_size, 1.5).unsqueeze(1)
-    _2D_window = _1D_window.mm(_1D_window.t()).float().unsqueeze(0).unsqueeze(0)
-    return _2D_window.expand(channel, 1, window_size, window_size).contiguous()
+def _window_2d(window_size, sigma=1.5):
+    """Normalised 1-D Gaussian (python-float exp, float32 tensor, float32 normalisation -- the arithmetic of
+    utils/loss_utils.py:25-27) and its outer product, the [ws, ws] window of create_window (:29-33)."""
+    centre = window_size // 2
+    taps = torch.tensor([exp(-((i - centre) ** 2) / (2.0 * sigma * sigma)) for i in range(window_size)], dtype=torch.float32)
+    taps = taps / taps.sum()
+    return torch.outer(taps, taps)
 
 
 def ssim_torch(img1, img2, window_size=11, size_average=True):
-    channel = img1.size(-3)
-    window = create_window(window_size, channel).to(img1.device).type_as(img1)
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
-    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
-    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
-    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    if size_average:
-        return ssim_map.mean()
-    return ssim_map.mean(1).mean(1).mean(1)
+    """SSIM as the reference formulates it (utils/loss_utils.py:36-66): depth-wise conv2d with the Gaussian window, zero padding."""
+    C = img1.size(-3)
+    win = _window_2d(window_size).to(device=img1.device, dtype=img1.dtype).expand(C, 1, window_size, window_size).contiguous()
+    blur = lambda t: F.conv2d(t, win, padding=window_size // 2, groups=C)  # noqa: E731
+    m1, m2 = blur(img1), blur(img2)
+    m11, m22, m12 = m1 * m1, m2 * m2, m1 * m2
+    v1, v2, v12 = blur(img1 * img1) - m11, blur(img2 * img2) - m22, blur(img1 * img2) - m12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    smap = ((2 * m12 + c1) * (2 * v12 + c2)) / ((m11 + m22 + c1) * (v1 + v2 + c2))
+    return smap.mean() if size_average else smap.mean(1).mean(1).mean(1)
 
 
 class _SsimMap(torch.autograd.Function):
