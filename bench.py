@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); measure
 WORKLOADS = {
     "C2": dict(P=50_000, W=512, H=512, deg=0, backward=False, desc="50k Gaussians, SH0, 512x512, forward only"),
     "C3": dict(P=200_000, W=1024, H=1024, deg=3, backward=True, desc="200k Gaussians, SH3, 1024x1024, fwd+bwd, alpha-mask loss"),
-    "C5": dict(P=500_000, W=1024, H=1024, deg=3, backward=True, log_scale=math.log(0.005),
-               desc="500k Gaussians, SH3, 1024x1024, fwd+bwd (scale 0.005)"),
+    "C5": dict(P=500_000, W=1024, H=1024, deg=3, backward=True, log_scale=math.log(0.005), sh_half=True,
+               desc="500k Gaussians, SH3 stored as fp16, 1024x1024, fwd+bwd (scale 0.005)"),
 }
 
 
@@ -192,6 +192,8 @@ def main():
     to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
     params = dict(means3D=to(g["means3D"]), shs=to(g["shs"]), opacities=to(g["opacities"]), scales=to(g["scales"]),
                   rotations=to(g["rotations"]))
+    if wl.get("sh_half"):
+        params["shs"] = params["shs"].half()  # fp16 SH storage (BASELINE configs[4]); gradients stay fp32
     camd = dict(cam, viewmatrix=to(cam["viewmatrix"]), projmatrix=to(cam["projmatrix"]), campos=to(cam["campos"]))
     bg, gt_d, mask_d = to(bg_np), to(gt), to(mask)
     step = parallel.ViewParallelStep(params, deg, camd, bg) if wl["backward"] else None

@@ -138,8 +138,12 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
  * dL_dout_extra = HOST array of n_extra / 3 device pointers, one [3][H][W] gradient image per colour triple, and returns
  * dL_dextra[P][n_extra], every geometric gradient being the sum over all images.  A null entry = that image received no
  * gradient: it is treated as zero and costs no work -- a training loss typically touches two or three of the six feature
- * images (train.py:256-286).  With extra_features == NULL / n_extra == 0 the _ex entry points are
+ * images (train.py:256-286).  sh_dtype: GSR_SH_F32 or GSR_SH_F16 (how the `shs` pointer is to be read).
+ * With extra_features == NULL / n_extra == 0 and GSR_SH_F32 the _ex entry points are
  * identical to the plain ones. */
+#define GSR_SH_F32 0 /* shs: float32 [P][M][3] */
+#define GSR_SH_F16 1 /* shs: IEEE half [P][16][3] (extension: fp16 SH storage, BASELINE configs[4]); M must be 16, the array
+                      * 16-byte aligned; coefficients are widened exactly on load, dL_dsh stays float32 */
 int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
                              gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
                              int height, const float *means3D, const float *shs, const float *colors_precomp,
@@ -147,7 +151,7 @@ int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, g
                              const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
                              float tan_fovx, float tan_fovy, int prefiltered, float *out_color, float *out_depth,
                              float *out_alpha, int *radii, int debug, int *host_num_rendered, const float *extra_features,
-                             int n_extra, float *out_extra, gsr_stream_t stream);
+                             int n_extra, float *out_extra, int sh_dtype, gsr_stream_t stream);
 int gsr_rasterize_forward_async_ex(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
                                    int D, int M, const float *background, int width, int height, const float *means3D,
                                    const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
@@ -155,7 +159,7 @@ int gsr_rasterize_forward_async_ex(char *geom_buffer, char *binning_buffer, size
                                    const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
                                    float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
                                    int *radii, int debug, uint32_t *dev_status, const float *extra_features, int n_extra,
-                                   float *out_extra, gsr_stream_t stream);
+                                   float *out_extra, int sh_dtype, gsr_stream_t stream);
 int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
                               const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
                               float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
@@ -164,7 +168,7 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
                               const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
                               float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                               float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
-                              const float *const *dL_dout_extra, float *dL_dextra, gsr_stream_t stream);
+                              const float *const *dL_dout_extra, float *dL_dextra, int sh_dtype, gsr_stream_t stream);
 
 /* Fused gradient of L = mean|color - gt| + lambda_alpha * mean (alpha - mask)^2 (train.py:261-262 with the masks set to
  * the whole image): dL_dcolor[3][H][W] = sign(color - gt) / (3 H W), dL_dalpha[H][W] = 2 lambda (alpha - mask) / (H W). */

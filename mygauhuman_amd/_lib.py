@@ -28,6 +28,7 @@ GSR_OK = 0
 Q = dict(DEPTHS=0, MEANS2D=1, CONIC_OPACITY=2, RGB=3, COV3D=4, TILES_TOUCHED=5, POINT_OFFSETS=6, CLAMPED=7,
          POINT_LIST=8, KEYS_SORTED=9, RANGES=10, FINAL_T=11, N_CONTRIB=12)
 BINNING_GLOBAL_RADIX, BINNING_TILE_BUCKET = 0, 1
+SH_F32, SH_F16 = 0, 1  # sh_dtype of the _ex entry points
 N_EXTRA = 18  # extra feature channels of the fused multi-feature blend (six RGB triples)
 DEFAULT_BINNING = BINNING_TILE_BUCKET
 DEFAULT_TILE_CULL = 1  # tuning knob "tile_cull": exact ellipse-vs-tile culling in the tile-bucket back-end
@@ -72,9 +73,9 @@ def _load():
     lib.gsr_rasterize_forward_async.restype = C.c_int
     lib.gsr_alpha_mask_loss_backward.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, C.c_float, fp, fp, vp]
     lib.gsr_alpha_mask_loss_backward.restype = C.c_int
-    lib.gsr_rasterize_forward_ex.argtypes = lib.gsr_rasterize_forward.argtypes[:-1] + [fp, C.c_int, fp, vp]
-    lib.gsr_rasterize_forward_async_ex.argtypes = lib.gsr_rasterize_forward_async.argtypes[:-1] + [fp, C.c_int, fp, vp]
-    lib.gsr_rasterize_backward_ex.argtypes = lib.gsr_rasterize_backward.argtypes[:-1] + [fp, C.c_int, C.POINTER(C.c_void_p), fp, vp]
+    lib.gsr_rasterize_forward_ex.argtypes = lib.gsr_rasterize_forward.argtypes[:-1] + [fp, C.c_int, fp, C.c_int, vp]
+    lib.gsr_rasterize_forward_async_ex.argtypes = lib.gsr_rasterize_forward_async.argtypes[:-1] + [fp, C.c_int, fp, C.c_int, vp]
+    lib.gsr_rasterize_backward_ex.argtypes = lib.gsr_rasterize_backward.argtypes[:-1] + [fp, C.c_int, C.POINTER(C.c_void_p), fp, C.c_int, vp]
     for _n in ("gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex"):
         getattr(lib, _n).restype = C.c_int
     lib.gsr_query_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]

@@ -99,10 +99,23 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
   if (STAGE_SH) {
     const int first = blockIdx.x * PRE_BLOCK;
     const int nrows = min(PRE_BLOCK, a.P - first);
-    const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * SH_ROW);
-    for (int q = threadIdx.x; q < nrows * (SH_ROW / 4); q += PRE_BLOCK) {
-      const int row = q / (SH_ROW / 4), k4 = q % (SH_ROW / 4);
-      *reinterpret_cast<float4 *>(&s_sh[row * SH_LDS_ROW + 4 * k4]) = slab[q];
+    if (a.sh_half) {
+      // fp16 storage: 96-byte rows, 16-byte chunks of 8 halves, widened to fp32 on the way into LDS (exact)
+      const uint4 *slab = reinterpret_cast<const uint4 *>(reinterpret_cast<const _Float16 *>(a.shs) + (size_t)first * SH_ROW);
+      for (int q = threadIdx.x; q < nrows * (SH_ROW / 8); q += PRE_BLOCK) {
+        const int row = q / (SH_ROW / 8), k8 = q % (SH_ROW / 8);
+        const uint4 v = slab[q];
+        const _Float16 *hv = reinterpret_cast<const _Float16 *>(&v);
+        float *dst = &s_sh[row * SH_LDS_ROW + 8 * k8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) dst[e] = (float)hv[e];
+      }
+    } else {
+      const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * SH_ROW);
+      for (int q = threadIdx.x; q < nrows * (SH_ROW / 4); q += PRE_BLOCK) {
+        const int row = q / (SH_ROW / 4), k4 = q % (SH_ROW / 4);
+        *reinterpret_cast<float4 *>(&s_sh[row * SH_LDS_ROW + 4 * k4]) = slab[q];
+      }
     }
     __syncthreads();
   }
@@ -206,6 +219,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
 int launch_preprocess_forward(const PreprocessArgs &a, hipStream_t stream) {
   if (a.P <= 0) return GSR_OK;
   const bool stage = a.shs && !a.colors_precomp && a.M == SH_M && (reinterpret_cast<size_t>(a.shs) % 16 == 0);
+  if (a.sh_half && a.shs && !a.colors_precomp && !stage) {
+    set_error("fp16 SH storage needs 16 coefficients per Gaussian and a 16-byte aligned array");
+    return GSR_EINVAL;
+  }
   if (stage)
     hipLaunchKernelGGL(preprocess_forward_kernel<true>, dim3(pre_blocks(a.P)), dim3(PRE_BLOCK), 0, stream, a);
   else

@@ -190,6 +190,7 @@ struct FwdIn {
   const float *extra;  // optional [P][n_extra] feature channels for the fused multi-feature blend
   int n_extra;
   float *out_extra;    // [n_extra][H][W]
+  int sh_half;         // 1: shs are IEEE halves
 };
 
 int validate_forward(const FwdIn &in, const char *who) {
@@ -248,6 +249,7 @@ int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStrea
   pa.radii = radii;
   pa.geom = geom;
   pa.prefiltered = in.prefiltered;
+  pa.sh_half = in.sh_half;
   prof_begin(PROF_PREPROCESS_FWD, stream);
   int rc = launch_preprocess_forward(pa, stream);
   prof_end(PROF_PREPROCESS_FWD, stream);
@@ -329,7 +331,7 @@ int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, g
                              const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
                              float tan_fovx, float tan_fovy, int prefiltered, float *out_color, float *out_depth,
                              float *out_alpha, int *radii, int debug, int *host_num_rendered, const float *extra_features,
-                             int n_extra, float *out_extra, gsr_stream_t stream_) {
+                             int n_extra, float *out_extra, int sh_dtype, gsr_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (host_num_rendered) *host_num_rendered = 0;
   if (!geometry_alloc || !binning_alloc || !image_alloc || !host_num_rendered) {
@@ -338,7 +340,7 @@ int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, g
   }
   const FwdIn in = {P, D, M, width, height, prefiltered, debug, background, means3D, shs, colors_precomp, opacities, scales,
                     rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, scale_modifier, tan_fovx, tan_fovy, out_color,
-                    out_depth, out_alpha, radii, extra_features, n_extra, out_extra};
+                    out_depth, out_alpha, radii, extra_features, n_extra, out_extra, sh_dtype == GSR_SH_F16 ? 1 : 0};
   int rc = validate_forward(in, "gsr_rasterize_forward");
   if (rc != GSR_OK) return rc;
   if (P == 0) return GSR_OK;  // DGR/rasterize_points.cu:84
@@ -394,7 +396,8 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
   return gsr_rasterize_forward_ex(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M,
                                   background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                                   rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
-                                  out_color, out_depth, out_alpha, radii, debug, host_num_rendered, nullptr, 0, nullptr, stream);
+                                  out_color, out_depth, out_alpha, radii, debug, host_num_rendered, nullptr, 0, nullptr, GSR_SH_F32,
+                                  stream);
 }
 
 int gsr_rasterize_forward_async_ex(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,
@@ -404,11 +407,11 @@ int gsr_rasterize_forward_async_ex(char *geom_buffer, char *binning_buffer, size
                                    const float *viewmatrix, const float *projmatrix, const float *cam_pos, float tan_fovx,
                                    float tan_fovy, int prefiltered, float *out_color, float *out_depth, float *out_alpha,
                                    int *radii, int debug, uint32_t *dev_status, const float *extra_features, int n_extra,
-                                   float *out_extra, gsr_stream_t stream_) {
+                                   float *out_extra, int sh_dtype, gsr_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const FwdIn in = {P, D, M, width, height, prefiltered, debug, background, means3D, shs, colors_precomp, opacities, scales,
                     rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, scale_modifier, tan_fovx, tan_fovy, out_color,
-                    out_depth, out_alpha, radii, extra_features, n_extra, out_extra};
+                    out_depth, out_alpha, radii, extra_features, n_extra, out_extra, sh_dtype == GSR_SH_F16 ? 1 : 0};
   int rc = validate_forward(in, "gsr_rasterize_forward_async");
   if (rc != GSR_OK) return rc;
   if (!geom_buffer || !binning_buffer || !image_buffer || !dev_status || P <= 0) {
@@ -436,7 +439,8 @@ int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t 
   return gsr_rasterize_forward_async_ex(geom_buffer, binning_buffer, binning_capacity, image_buffer, P, D, M, background, width,
                                         height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
-                                        out_color, out_depth, out_alpha, radii, debug, dev_status, nullptr, 0, nullptr, stream);
+                                        out_color, out_depth, out_alpha, radii, debug, dev_status, nullptr, 0, nullptr, GSR_SH_F32,
+                                        stream);
 }
 
 int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
@@ -447,7 +451,7 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
                               const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
                               float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                               float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
-                              const float *const *dL_dout_extra, float *dL_dextra, gsr_stream_t stream_) {
+                              const float *const *dL_dout_extra, float *dL_dextra, int sh_dtype, gsr_stream_t stream_) {
   (void)alphas;  // unused by the reference kernel as well (CR/backward.cu:410)
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (P < 0 || R < 0 || width <= 0 || height <= 0) {
@@ -532,6 +536,7 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   pb.grad_rows = geom.grad_rows;
   pb.grow = grow;
   pb.CE = n_extra;
+  pb.sh_half = sh_dtype == GSR_SH_F16 ? 1 : 0;
   pb.dL_dextra = dL_dextra;
   pb.recs = geom.recs;
   pb.dL_dmean2D = dL_dmean2D;
@@ -563,7 +568,7 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
                                    scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
                                    radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D,
                                    dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug,
-                                   nullptr, 0, nullptr, nullptr, stream);
+                                   nullptr, 0, nullptr, nullptr, GSR_SH_F32, stream);
 }
 
 int gsr_query_state(int what, int P, int R, int width, int height, const char *geom_buffer, const char *binning_buffer,

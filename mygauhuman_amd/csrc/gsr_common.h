@@ -156,6 +156,7 @@ struct PreprocessArgs {
   int *radii;
   GeomState geom;
   int prefiltered;
+  int sh_half;  // 1: shs points at IEEE half coefficients [P][16][3] (extension: fp16 SH storage), converted while staging
 };
 int launch_preprocess_forward(const PreprocessArgs &a, hipStream_t stream);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t stream);
@@ -217,6 +218,7 @@ struct PreprocessBwdArgs {
   float *dL_dextra;  // [P][CE]
   const SplatRec *recs;
   float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale, *dL_drot;
+  int sh_half;  // 1: shs are IEEE halves (see PreprocessArgs)
 };
 int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream);
 

@@ -235,10 +235,22 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(const Preproce
   if (STAGE_SH) {
     const int first = blockIdx.x * 256;
     const int nrows = min(256, a.P - first);
-    const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * BSH_ROW);
-    for (int q = threadIdx.x; q < nrows * (BSH_ROW / 4); q += 256) {
-      const int row = q / (BSH_ROW / 4), k4 = q % (BSH_ROW / 4);
-      *reinterpret_cast<float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * k4]) = slab[q];
+    if (a.sh_half) {  // fp16 storage (see geometry.hip); the gradient that leaves below is fp32 either way
+      const uint4 *slab = reinterpret_cast<const uint4 *>(reinterpret_cast<const _Float16 *>(a.shs) + (size_t)first * BSH_ROW);
+      for (int q = threadIdx.x; q < nrows * (BSH_ROW / 8); q += 256) {
+        const int row = q / (BSH_ROW / 8), k8 = q % (BSH_ROW / 8);
+        const uint4 v = slab[q];
+        const _Float16 *hv = reinterpret_cast<const _Float16 *>(&v);
+        float *dst = &s_sh[row * BSH_LDS_ROW + 8 * k8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) dst[e] = (float)hv[e];
+      }
+    } else {
+      const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * BSH_ROW);
+      for (int q = threadIdx.x; q < nrows * (BSH_ROW / 4); q += 256) {
+        const int row = q / (BSH_ROW / 4), k4 = q % (BSH_ROW / 4);
+        *reinterpret_cast<float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * k4]) = slab[q];
+      }
     }
     __syncthreads();
     if (i < a.P) preprocess_backward_one(a, i, &s_sh[threadIdx.x * BSH_LDS_ROW], &s_sh[threadIdx.x * BSH_LDS_ROW]);
@@ -258,6 +270,10 @@ int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream) {
   if (a.P <= 0) return GSR_OK;
   const bool stage = a.shs && a.M == BSH_M && (reinterpret_cast<size_t>(a.shs) % 16 == 0) &&
                      (reinterpret_cast<size_t>(a.dL_dsh) % 16 == 0);
+  if (a.sh_half && a.shs && !stage) {
+    set_error("fp16 SH storage needs 16 coefficients per Gaussian and 16-byte aligned arrays");
+    return GSR_EINVAL;
+  }
   if (stage)
     hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
   else

@@ -15,6 +15,13 @@ def _f32c(t, name):
     return t.contiguous()  # silent copy for non-contiguous inputs, DGR/rasterize_points.cu:97-116
 
 
+def _sh(t):
+    """SH coefficients: float32 like the reference, or float16 storage (extension) -> (contiguous tensor, sh_dtype flag)."""
+    if t.numel() and t.dtype == torch.float16:
+        return t.contiguous(), _lib.SH_F16
+    return _f32c(t, "sh"), _lib.SH_F32
+
+
 def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -71,7 +78,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         M = sh.size(1) if sh.numel() != 0 else 0
         means3D, colors, opacity = _f32c(means3D, "means3D"), _f32c(colors, "colors"), _f32c(opacity, "opacity")
         scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
-        sh, background = _f32c(sh, "sh"), _f32c(background, "background")
+        (sh, sh_dtype), background = _sh(sh), _f32c(background, "background")
         viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
         with torch.cuda.device(dev):
             rc = lib.gsr_rasterize_forward_ex(
@@ -80,7 +87,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 ptr(cov3D_precomp), ptr(viewmatrix), ptr(projmatrix), ptr(campos), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
                 radii.data_ptr(), int(bool(debug)), C.byref(rendered), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
-                None if out_extra is None else out_extra.data_ptr(), _stream(dev))
+                None if out_extra is None else out_extra.data_ptr(), sh_dtype, _stream(dev))
         for s in (geom, binning, img):
             if s.error is not None:
                 raise s.error
@@ -188,7 +195,7 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
     M = sh.size(1) if sh.numel() != 0 else 0
     means3D, colors, opacity = _f32c(means3D, "means3D"), _f32c(colors, "colors"), _f32c(opacity, "opacity")
     scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
-    sh, background = _f32c(sh, "sh"), _f32c(background, "background")
+    (sh, sh_dtype), background = _sh(sh), _f32c(background, "background")
     viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
     with torch.cuda.device(dev):
         rc = lib.gsr_rasterize_forward_async_ex(
@@ -197,7 +204,7 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
             ptr(viewmatrix), ptr(projmatrix), ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
             out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr(), int(bool(debug)),
             status.data_ptr(), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
-            None if out_extra is None else out_extra.data_ptr(), _stream(dev))
+            None if out_extra is None else out_extra.data_ptr(), sh_dtype, _stream(dev))
         check(rc, "gsr_rasterize_forward_async")
         watch = AsyncCapacity.watch(status, cap)
     return cap, out_color, out_depth, out_alpha, radii, geom, binning, img, out_extra, watch
@@ -251,7 +258,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P != 0:
         means3D, colors = _f32c(means3D, "means3D"), _f32c(colors, "colors")
         scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
-        sh, background, alphas = _f32c(sh, "sh"), _f32c(background, "background"), _f32c(alphas, "alphas")
+        (sh, sh_dtype), background, alphas = _sh(sh), _f32c(background, "background"), _f32c(alphas, "alphas")
         viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
         dL_dout_color, dL_dout_depth = _f32c(dL_dout_color, "dL_dout_color"), _f32c(dL_dout_depth, "dL_dout_depth")
         dL_dout_alpha = _f32c(dL_dout_alpha, "dL_dout_alpha")
@@ -266,7 +273,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
                 ptr(extra), 0 if extra is None else _lib.N_EXTRA, None if extra is None else extra_ptrs,
-                None if dL_dextra is None else dL_dextra.data_ptr(), _stream(dev))
+                None if dL_dextra is None else dL_dextra.data_ptr(), sh_dtype, _stream(dev))
         check(rc, "gsr_rasterize_backward")
     if extra is not None:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dextra

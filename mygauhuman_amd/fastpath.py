@@ -9,7 +9,7 @@ reports R and an overflow flag in `status` (checked with .overflowed(), which do
 """
 import torch
 
-from ._lib import check, lib
+from ._lib import SH_F16, SH_F32, check, lib
 
 
 class RasterSession:
@@ -51,13 +51,14 @@ class RasterSession:
     def forward(self, params, cam, bg, sh_degree, scale_modifier=1.0):
         """SH + scales/rotations input mode.  Returns (color, depth, alpha, radii) views owned by the session."""
         p = params
-        check(lib.gsr_rasterize_forward_async(
+        sh_dtype = SH_F16 if p["shs"].dtype == torch.float16 else SH_F32  # fp16 SH storage (extension): widened on load
+        check(lib.gsr_rasterize_forward_async_ex(
             self.geom.data_ptr(), self.bin.data_ptr(), self.capacity, self.img.data_ptr(), self.P, int(sh_degree), self.M,
             bg.data_ptr(), self.W, self.H, p["means3D"].data_ptr(), p["shs"].data_ptr(), None, p["opacities"].data_ptr(),
             p["scales"].data_ptr(), float(scale_modifier), p["rotations"].data_ptr(), None, cam["viewmatrix"].data_ptr(),
             cam["projmatrix"].data_ptr(), cam["campos"].data_ptr(), float(cam["tanfovx"]), float(cam["tanfovy"]), 0,
             self.color.data_ptr(), self.depth.data_ptr(), self.alpha.data_ptr(), self.radii.data_ptr(), 0,
-            self.status.data_ptr(), self._stream()), "gsr_rasterize_forward_async")
+            self.status.data_ptr(), None, 0, None, sh_dtype, self._stream()), "gsr_rasterize_forward_async")
         return self.color, self.depth, self.alpha, self.radii
 
     def alpha_mask_loss_backward(self, gt, mask, lambda_alpha=0.1):
@@ -69,7 +70,8 @@ class RasterSession:
     def backward(self, params, cam, bg, sh_degree, dL_dcolor, dL_ddepth, dL_dalpha, out, scale_modifier=1.0):
         """out: dict with means3D / sh / opacity / scales / rotations gradient tensors (written in place)."""
         p = params
-        check(lib.gsr_rasterize_backward(
+        sh_dtype = SH_F16 if p["shs"].dtype == torch.float16 else SH_F32
+        check(lib.gsr_rasterize_backward_ex(
             self.P, int(sh_degree), self.M, self.capacity, bg.data_ptr(), self.W, self.H, p["means3D"].data_ptr(),
             p["shs"].data_ptr(), None, self.alpha.data_ptr(), p["scales"].data_ptr(), float(scale_modifier),
             p["rotations"].data_ptr(), None, cam["viewmatrix"].data_ptr(), cam["projmatrix"].data_ptr(),
@@ -77,7 +79,8 @@ class RasterSession:
             self.geom.data_ptr(), self.bin.data_ptr(), self.img.data_ptr(), dL_dcolor.data_ptr(), dL_ddepth.data_ptr(),
             dL_dalpha.data_ptr(), self.dL_dmean2D.data_ptr(), self.dL_dconic.data_ptr(), out["opacity"].data_ptr(),
             self.dL_dcolors.data_ptr(), out["means3D"].data_ptr(), self.dL_dcov3D.data_ptr(), out["sh"].data_ptr(),
-            out["scales"].data_ptr(), out["rotations"].data_ptr(), 0, self._stream()), "gsr_rasterize_backward")
+            out["scales"].data_ptr(), out["rotations"].data_ptr(), 0, None, 0, None, None, sh_dtype, self._stream()),
+            "gsr_rasterize_backward")
 
     def num_rendered(self):
         """R of the last forward (synchronises)."""

@@ -230,3 +230,40 @@ def test_async_session_matches_sync_path_and_reports_overflow(oracle):
     col, _, _, _ = small.forward(params, camd, bg, 3)
     assert small.overflowed() and small.num_rendered() == R
     np.testing.assert_array_equal(col.cpu().numpy(), np.broadcast_to(bg.cpu().numpy()[:, None, None], (3, H, W)))
+
+
+@pytest.mark.parametrize("P,W,H", [(5000, 150, 100), (300, 64, 48)])
+def test_fp16_sh_storage_equals_fp32_on_rounded_coefficients(P, W, H):
+    """fp16 SH storage (BASELINE configs[4]): halves are widened exactly on load, so every output must be BIT-identical to
+    the fp32 path fed with the same (fp16-rounded) coefficients; dL_dsh comes back in fp32."""
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    from mygauhuman_amd.fastpath import RasterSession
+    cam, g = util.make_scene(P, W, H, 12, 3)
+    sh16 = util.to_dev(g["shs"]).half()
+    sh32 = sh16.float()
+    bg = util.to_dev(np.array([0.2, 0.3, 0.4], np.float32))
+    d = util.to_dev
+    e = torch.empty(0)
+    args = lambda sh: (bg, d(g["means3D"]), e, d(g["opacities"]), d(g["scales"]), d(g["rotations"]), 1.0, e, d(cam["viewmatrix"]),  # noqa: E731
+                       d(cam["projmatrix"]), cam["tanfovx"], cam["tanfovy"], H, W, sh, 3, d(cam["campos"]), False, False)
+    a, b = _C.rasterize_gaussians(*args(sh16)), _C.rasterize_gaussians(*args(sh32))
+    assert a[0] == b[0]
+    for x, y in zip(a[1:5], b[1:5]):
+        assert torch.equal(x, y)
+    rng = np.random.default_rng(0)
+    dc, dd, da = (d(rng.normal(0, 1, s).astype(np.float32)) for s in ((3, H, W), (1, H, W), (1, H, W)))
+    bw = lambda out, sh: _C.rasterize_gaussians_backward(bg, d(g["means3D"]), out[4], e, d(g["scales"]), d(g["rotations"]), 1.0, e,  # noqa: E731
+                                                         d(cam["viewmatrix"]), d(cam["projmatrix"]), cam["tanfovx"], cam["tanfovy"], dc, dd, da,
+                                                         sh, 3, d(cam["campos"]), out[5], out[0], out[6], out[7], out[3], False)
+    ga, gb = bw(a, sh16), bw(b, sh32)
+    assert ga[5].dtype == torch.float32 and ga[5].shape == (P, 16, 3)
+    for x, y in zip(ga, gb):   # atomics sum in arbitrary order: equal to rounding
+        util.assert_close("grad", x.cpu().numpy(), y.cpu().numpy(), tol=2e-5, max_bad_frac=1e-4)
+    # the sync-free session takes the half tensor as well
+    params = dict(means3D=d(g["means3D"]), shs=sh16, opacities=d(g["opacities"]), scales=d(g["scales"]), rotations=d(g["rotations"]))
+    camd = dict(cam, viewmatrix=d(cam["viewmatrix"]), projmatrix=d(cam["projmatrix"]), campos=d(cam["campos"]))
+    s = RasterSession(P, W, H, 16, "cuda", capacity=a[0] + 1000)
+    col, dep, alp, rad = s.forward(params, camd, bg, 3)
+    assert torch.equal(col, a[1]) and torch.equal(rad, a[4])
+    with pytest.raises(RuntimeError):   # only the 16-coefficient layout has a half path
+        _C.rasterize_gaussians(*args(sh16[:, :9].contiguous()))
