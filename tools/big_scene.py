@@ -1,3 +1,4 @@
+"""Stress run: 1M Gaussians, SH3, 4096x4096, forward + loss gradient + backward through the sync-free session (finite outputs, no overflow)."""
 import sys, numpy as np, torch, math, time
 sys.path.insert(0, '/root/repo')
 from mygauhuman_amd import synthetic, cameras, parallel
