@@ -149,7 +149,14 @@ def pmc_traffic(stage, workload):
         return {"traffic": None}
     for r in csv.DictReader(open(files[-1])):
         if r["kernel"] == PMC_KERNEL[stage]:
-            return {"traffic": int(float(r["fetch_bytes_x2"]) + float(r["write_bytes"])),
+            extra = {}
+            try:  # vector-ALU occupancy of the kernel: SQ_ACTIVE_INST_VALU counts quad-cycles over all SIMDs, SQ_BUSY_CYCLES
+                # cycles summed over the 32 shader engines -> busy SIMD-cycles / (kernel cycles x 1024 SIMDs)
+                busy = 4.0 * float(r["SQ_ACTIVE_INST_VALU_per_launch"]) / (float(r["SQ_BUSY_CYCLES_per_launch"]) / 32.0 * 1024.0)
+                extra = {"valu_busy_frac_pmc": round(min(busy, 1.0), 3)}
+            except (KeyError, ZeroDivisionError, ValueError):
+                pass
+            return {**extra, "traffic": int(float(r["fetch_bytes_x2"]) + float(r["write_bytes"])),
                     "traffic_source": "profiles/" + os.path.basename(files[-1]) + " (2 x FETCH_SIZE + WRITE_SIZE per launch; "
                                       "WRITE_SIZE counts every float-atomic lane as 4 B)"}
     return {"traffic": None}
