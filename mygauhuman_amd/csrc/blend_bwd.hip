@@ -61,6 +61,19 @@ __device__ __forceinline__ float fold16(float x, float y) {
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
+// the same folds, also handing back the part that came from the upper lanes / odd rows: for lane = 32 b2 + 16 b1 + 8 b0 + lx
+// these are the b2 = 1 and b1 = 1 terms, from which the y-moments follow without accumulating r dy and r dy^2 per lane
+__device__ __forceinline__ float fold32_parts(float a, float b, float &hi) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  hi = __uint_as_float(r.y);
+  return __uint_as_float(r.x) + hi;
+}
+__device__ __forceinline__ float fold16_parts(float x, float y, float &odd) {
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  odd = __uint_as_float(r.y);
+  return __uint_as_float(r.x) + odd;
+}
+
 // GROW row columns 0..8: with r = G * dL_dalpha(pair) and d = mean2D - pixel:
 //   [0] sum r*dx  [1] sum r*dy  [2] sum r*dx*dx  [3] sum r*dx*dy  [4] sum r*dy*dy  [5] sum r (= dL_dopacity)
 //   [6..8] dL_dcolor.  The geometric gradients are linear in these moments (CR/backward.cu:567-580):
@@ -91,7 +104,12 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   // x-weights (dx is a function of lx alone) are applied there, two values are packed into the two half rows, and three DPP
   // steps over 8 lanes finish: 18 permlane swaps + 19 DPP per four Gaussians instead of 27 + 36.
   constexpr bool SEP = (SLOTS == 1 && RED == 0);
-  constexpr int NA = SEP ? 6 : NACC;
+  // HIER (with SEP): only sum r is kept per lane; with ly = 4 b2 + 2 b1 + b0 the folds over b2, b1, b0 also hand back their
+  // "bit set" halves, so that  sum r ly = 4 E[b2] + 2 E[b1] + E[b0]  and  sum r ly^2 = 16 E[b2] + 4 E[b1] + E[b0] + 16 E[b2 b1]
+  // + 8 E[b2 b0] + 4 E[b1 b0]  come out of 4 swaps instead of 9, and the moments about the Gaussian follow from
+  // dy = Dy - ly (Dy = mean.y - top row of the quadrant).
+  constexpr bool HIER = SEP;
+  constexpr int NA = SEP ? (HIER ? 4 : 6) : NACC;
   __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
@@ -250,7 +268,12 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
                 T[s] = Tn;
                 // moments of r = G * dL_dalpha over the pixels; preprocess_bwd.hip turns them into dL_dmean2D / dL_dconic
                 const float r = G * dL_dalpha;
-                if constexpr (SEP) {
+                if constexpr (SEP && HIER) {
+                  acc[u][0] += r;  // the x- and y-weights are applied after the folds
+                  acc[u][1] += w * dpix0[s];
+                  acc[u][2] += w * dpix1[s];
+                  acc[u][3] += w * dpix2[s];
+                } else if constexpr (SEP) {
                   // only the y-weights go in per lane; the x-weights are applied to the COLUMN sums after the folds
                   const float ry = r * dy;
                   acc[u][0] += r;
@@ -281,17 +304,44 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
         const bool row_live = ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
         const uint32_t gid = row_live ? s_id[g + u_of_row] : 0u;
         if constexpr (SEP) {
-          float c[NA];
+          const float2 gxy = *reinterpret_cast<const float2 *>(&s0[g + u_of_row]);  // this row's Gaussian centre
+          const float dxr = gxy.x - pxf[0];                // against this lane's column
+          float qa, qb, qc, ka, kb;
+          if constexpr (HIER) {
+            float a1ab, a1cd, b1, d1;
+            const float a0ab = fold32_parts(acc[0][0], acc[1][0], a1ab), a0cd = fold32_parts(acc[2][0], acc[3][0], a1cd);
+            const float b0 = fold16_parts(a0ab, a0cd, b1);  // sum over b2, b1      | b1 = 1 part
+            const float d0 = fold16_parts(a1ab, a1cd, d1);  // b2 = 1, sum over b1  | b2 = b1 = 1 part
+            const float b0t = dpp_f<0x128>(b0), b1t = dpp_f<0x128>(b1), d0t = dpp_f<0x128>(d0), d1t = dpp_f<0x128>(d1);
+            const float e0 = b0 + b0t, e_b0 = upper ? b0 : b0t;
+            const float e_b1 = b1 + b1t, e_b1b0 = upper ? b1 : b1t;
+            const float e_b2 = d0 + d0t, e_b2b0 = upper ? d0 : d0t;
+            const float e_b2b1 = d1 + d1t;
+            const float s1 = 4.f * e_b2 + 2.f * e_b1 + e_b0;
+            const float s2 = 16.f * (e_b2 + e_b2b1) + 4.f * (e_b1 + e_b1b0) + 8.f * e_b2b0 + e_b0;
+            const float Dy = gxy.y - (pyf[0] - (float)(lane >> 3));  // mean.y - top pixel row of the quadrant
+            const float c1 = Dy * e0 - s1;                           // column sum of r dy
+            const float c2 = Dy * (Dy * e0 - 2.f * s1) + s2;         // column sum of r dy^2
+            qa = upper ? c1 : e0;
+            qb = qa * dxr;
+            qc = upper ? c2 : qb * dxr;
+            const float k0 = fold16(fold32(acc[0][1], acc[1][1]), fold32(acc[2][1], acc[3][1]));
+            const float k1 = fold16(fold32(acc[0][2], acc[1][2]), fold32(acc[2][2], acc[3][2]));
+            const float k2 = fold16(fold32(acc[0][3], acc[1][3]), fold32(acc[2][3], acc[3][3]));
+            ka = pack_halves(k0, k1, upper);
+            kb = k2 + dpp_f<0x128>(k2);
+          } else {
+            float c[NA];
 #pragma unroll
-          for (int k = 0; k < NA; k++) c[k] = fold16(fold32(acc[0][k], acc[1][k]), fold32(acc[2][k], acc[3][k]));
-          // lane j of a row now holds the sum over ly = (j >> 3) mod 2 of column lx = j & 7
-          const float dxr = s0[g + u_of_row].x - pxf[0];  // this row's Gaussian against this lane's column
-          float qa = pack_halves(c[0], c[1], upper);       // lower: col-sum r        upper: col-sum r dy
-          float qb = qa * dxr;                             // lower: col-sum r dx     upper: col-sum r dx dy
-          const float c2 = c[2] + dpp_f<0x128>(c[2]);      // col-sum r dy^2 (used by the upper half)
-          float qc = upper ? c2 : qb * dxr;                // lower: col-sum r dx^2   upper: col-sum r dy^2
-          float ka = pack_halves(c[3], c[4], upper);       // lower: red              upper: green
-          float kb = c[5] + dpp_f<0x128>(c[5]);            // blue in both halves
+            for (int k = 0; k < NA; k++) c[k] = fold16(fold32(acc[0][k], acc[1][k]), fold32(acc[2][k], acc[3][k]));
+            // lane j of a row now holds the sum over ly = (j >> 3) mod 2 of column lx = j & 7
+            qa = pack_halves(c[0], c[1], upper);            // lower: col-sum r        upper: col-sum r dy
+            qb = qa * dxr;                                  // lower: col-sum r dx     upper: col-sum r dx dy
+            const float c2 = c[2] + dpp_f<0x128>(c[2]);     // col-sum r dy^2 (used by the upper half)
+            qc = upper ? c2 : qb * dxr;                     // lower: col-sum r dx^2   upper: col-sum r dy^2
+            ka = pack_halves(c[NA - 3], c[NA - 2], upper);  // lower: red              upper: green
+            kb = c[NA - 1] + dpp_f<0x128>(c[NA - 1]);       // blue in both halves
+          }
           qa = half8_sum(qa);
           qb = half8_sum(qb);
           qc = half8_sum(qc);
