@@ -95,10 +95,26 @@ def main():
                         w2v_translate_scale=w2v_ts, proj=proj, full_proj=full.numpy(), camera_center=center.numpy(),
                         fovx=np.float64(focal2fov(float(K[0, 0]), W)), fovy=np.float64(focal2fov(float(K[1, 1]), H)),
                         pts=pts, ndc=ndc)
-    # ---- the reference's own data file for the PLY reader / writer: check/points3d.ply (an SMPL-shaped initial point cloud,
-    # written by plyfile through storePly, scene/dataset_readers.py:138-153) is copied unchanged -- data, not source
-    import shutil
-    shutil.copyfile(os.path.join(REF, "check", "points3d.ply"), os.path.join(HERE, "points3d.ply"))
+    # ---- PLY reader / writer: the reference's own data file check/points3d.ply (an SMPL-shaped initial point cloud written by
+    # plyfile through storePly, scene/dataset_readers.py:138-153) pins the on-disk format.  Committed: its first 256 vertices
+    # as a valid PLY (header count rewritten) + size / sha256 / bounding box / mean colour of the whole file.
+    import hashlib
+    import json
+    src = os.path.join(REF, "check", "points3d.ply")
+    data = open(src, "rb").read()
+    end = data.find(b"end_header\n") + len(b"end_header\n")
+    header = data[:end].decode("ascii")
+    n_total = int(header.split("element vertex ")[1].split()[0])
+    with open(os.path.join(HERE, "points3d_head256.ply"), "wb") as f:
+        f.write(header.replace(f"element vertex {n_total}", "element vertex 256").encode("ascii") + data[end:end + 256 * 27])
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from mygauhuman_amd import ply_io
+    v = ply_io.read_ply(src)
+    json.dump(dict(source="check/points3d.ply of the reference (binary_little_endian, written by plyfile through storePly)",
+                   vertices=int(len(v)), bytes=len(data), sha256=hashlib.sha256(data).hexdigest(), header=header,
+                   bbox_min=[float(v[k].min()) for k in "xyz"], bbox_max=[float(v[k].max()) for k in "xyz"],
+                   rgb_mean=[float(v[k].mean()) for k in ("red", "green", "blue")]),
+              open(os.path.join(HERE, "points3d_meta.json"), "w"), indent=1)
     print("golden vectors written to", HERE)
 
 

@@ -8,18 +8,28 @@ import torch
 from mygauhuman_amd import ply_io
 from mygauhuman_amd.scene_model import HumanGaussianModel
 
-GOLD = os.path.join(os.path.dirname(__file__), "golden", "points3d.ply")
+import json  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "points3d_head256.ply")
+META = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "points3d_meta.json")))
 
 
 def test_reference_point_cloud_reads_and_rewrites_byte_for_byte(tmp_path):
+    """tests/golden/points3d_head256.ply = the first 256 vertices of the reference's check/points3d.ply (written by plyfile),
+    points3d_meta.json = header / size / bounding box of the whole file (tests/golden/make_golden.py)."""
     pts, cols, nrm = ply_io.fetch_ply(GOLD)
-    assert pts.shape == (6890, 3) and cols.shape == (6890, 3) and nrm.shape == (6890, 3)   # one point per SMPL vertex
-    assert pts.dtype == np.float32 and 0.0 <= cols.min() and cols.max() <= 1.0
-    ext = pts.max(0) - pts.min(0)
-    assert 1.0 < ext.max() < 2.5 and np.isfinite(pts).all()          # a human body in metres
+    assert pts.shape == (256, 3) and cols.shape == (256, 3) and nrm.shape == (256, 3)
+    assert pts.dtype == np.float32 and 0.0 <= cols.min() and cols.max() <= 1.0 and np.isfinite(pts).all()
+    assert np.all(pts >= np.array(META["bbox_min"]) - 1e-6) and np.all(pts <= np.array(META["bbox_max"]) + 1e-6)
     out = tmp_path / "again.ply"
     ply_io.store_ply(str(out), pts, np.round(cols * 255.0), nrm)
-    assert out.read_bytes() == open(GOLD, "rb").read()
+    assert out.read_bytes() == open(GOLD, "rb").read()                       # same header text, same records
+    # the full file: 6890 vertices (one per SMPL vertex), header + 27 bytes per vertex, a human body in metres
+    assert META["vertices"] == 6890 and META["bytes"] == len(META["header"]) + 27 * META["vertices"]
+    hdr = open(GOLD, "rb").read().split(b"end_header\n")[0].decode() + "end_header\n"
+    assert hdr == META["header"].replace("element vertex 6890", "element vertex 256")
+    ext = np.array(META["bbox_max"]) - np.array(META["bbox_min"])
+    assert 1.0 < ext.max() < 2.5
 
 
 def test_gaussian_checkpoint_round_trip_and_layout(tmp_path):
