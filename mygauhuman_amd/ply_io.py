@@ -7,7 +7,7 @@ reference uses the `plyfile` package, which is not a dependency here):
                                       (SH stored channel-major: features.transpose(1, 2).flatten)
 Files are `binary_little_endian 1.0` with a single `vertex` element and the minimal header plyfile writes; the reader also
 accepts ascii files and the other scalar property types.  Pinned by the reference's own data file check/points3d.ply
-(tests/golden/points3d.ply): read + write reproduces it byte for byte.
+(its first 256 vertices are tests/golden/points3d_head256.ply): read + write reproduces them byte for byte.
 """
 import os
 
