@@ -182,3 +182,49 @@ def test_render_pipe_knobs_agree(oracle):
     assert float((out["render"] - base["render"]).abs().max()) > 1e-3            # different colours ...
     assert float((out["normal"] - base["normal"]).abs().max()) < 1e-5             # ... same geometry and feature images
     assert grads[1] is None or float(grads[1].abs().sum()) == 0.0                  # SH coefficients unused
+
+
+def test_pose_refinement_gradient_hip_chain_equals_torch_chain(oracle):
+    """A trainable pose-refinement module (correct_Rs with a parameter): the gradient that reaches it through render() ->
+    rasterizer -> attributes -> LBS (dA_pose partials, pose-offset GEMV backward) -> pose kernel must equal the one through the
+    reference's torch pose chain (lbs.POSE_CHAIN = "torch")."""
+    from mygauhuman_amd import lbs
+    from mygauhuman_amd.gaussian_renderer import render
+    s = _human_scene(oracle, seed=7, motion=True)
+
+    class PoseDec(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.delta = torch.nn.Parameter(0.02 * torch.randn((23, 3, 3), generator=g).cuda())
+
+        def forward(self, posevec):
+            return {"Rs": (torch.eye(3, device="cuda")[None] + self.delta)[None]}
+
+    class WDec(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1, 24, 1, device="cuda"))
+
+        def forward(self, pts):
+            return self.w.expand(1, 24, pts.shape[1])
+
+    dec, wdec = PoseDec(), WDec()
+    s.model.pose_decoder, s.model.lweight_offset_decoder = dec, wdec
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    bg = util.to_dev(np.zeros(3, np.float32))
+    w_img = torch.rand((3, s.cam_np["H"], s.cam_np["W"]), device="cuda")
+    grads = {}
+    for chain in ("hip", "torch"):
+        lbs.POSE_CHAIN = chain
+        try:
+            dec.delta.grad = None
+            wdec.w.grad = None
+            out = render(1, s.cam, s.model, pipe, bg)
+            ((out["render"] * w_img).sum() + out["normal"].mean()).backward()
+            grads[chain] = (dec.delta.grad.clone(), wdec.w.grad.clone())
+        finally:
+            lbs.POSE_CHAIN = "hip"
+    for a, b in zip(grads["hip"], grads["torch"]):
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) < 2e-3 * scale, (float((a - b).abs().max()), scale)
