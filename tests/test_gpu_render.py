@@ -228,3 +228,41 @@ def test_pose_refinement_gradient_hip_chain_equals_torch_chain(oracle):
     for a, b in zip(grads["hip"], grads["torch"]):
         scale = float(b.abs().max())
         assert scale > 0 and float((a - b).abs().max()) < 2e-3 * scale, (float((a - b).abs().max()), scale)
+
+
+def test_render_training_loop_with_densification(oracle):
+    """render() in a short Adam loop with densification statistics, a densify-and-prune (SMPL-distance prior included) and an
+    opacity reset between frames: shapes follow the changing Gaussian count, everything stays finite, the loss goes down."""
+    from mygauhuman_amd import densify, loss_utils
+    from mygauhuman_amd.gaussian_renderer import render
+    s = _human_scene(oracle, seed=9)
+    model = s.model
+    densify.training_setup(model, dict(xyz=2e-4, f_dc=5e-3, f_rest=2.5e-4, opacity=0.05, scaling=5e-3, rotation=1e-3, normal=1e-3,
+                                       albedo=0.02, roughness=0.02))
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    bg = util.to_dev(np.zeros(3, np.float32))
+    with torch.no_grad():
+        target = render(1, s.cam, model, pipe, bg)["render"].clone()
+        model._features_dc.add_(0.5 * torch.randn_like(model._features_dc))   # perturb the colours, then fit them back
+    verts = s.cam.big_pose_world_vertex
+    losses, counts = [], []
+    for it in range(1, 61):
+        o = render(it, s.cam, model, pipe, bg)
+        loss = loss_utils.l1_loss(o["render"], target) + 0.2 * (1.0 - loss_utils.ssim(o["render"][None], target[None]))
+        loss.backward()
+        with torch.no_grad():
+            densify.update_max_radii(model, o["radii"], o["visibility_filter"])
+            densify.add_densification_stats(model, o["viewspace_points"], o["visibility_filter"])
+            if it == 30:
+                densify.densify_and_prune(model, 1e-7, 0.005, 2.0, 20, t_vertices=verts)
+            if it == 45:
+                densify.reset_opacity(model)
+        model.optimizer.step()
+        model.optimizer.zero_grad(set_to_none=True)
+        losses.append(float(loss.detach()))
+        counts.append(model.get_xyz.shape[0])
+        assert o["radii"].shape[0] == counts[-1] or it == 30
+    assert all(np.isfinite(losses)) and np.mean(losses[25:29]) < 0.7 * np.mean(losses[:3])
+    assert counts[-1] != counts[0]
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
