@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X Gaussian-splat hot path.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (one rank per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE from the environment), or as plain `python bench.py --gpus N`, which starts its own N
+rank processes BEFORE anything touches the GPU and exits with their status.  With fewer devices than ranks (one-GPU box)
+the ranks share device 0 over gloo: a functional rehearsal of the view-parallel path, labelled as such, not a scaling number.
 
 A step = one pass of the hot path over one synthetic camera view: rasterizer forward (preprocess -> binning ->
 blend), the alpha-mask loss gradient (L1(color, gt) + 0.1 MSE(alpha, mask), train.py:261-262), rasterizer backward
-(blend backward -> backward preprocess) and, for N > 1, the RCCL all-reduce of the flat Gaussian-gradient bucket.
-Workload at N = 1: BASELINE.json configs[2] ("C3"): 200k Gaussians, SH degree 3, 1024x1024, fp32, seeded synthetic
-scene of SURVEY.md §8(d) (S-uniform).  For N > 1 every rank renders its own view of the same replica (weak scaling).
+(blend backward -> backward preprocess) and, for N > 1, the exchange of the Gaussian gradients (RCCL all-reduce of the
+flat bucket + compact SH all-gather).  Workload at N = 1: BASELINE.json configs[2] ("C3"): 200k Gaussians, SH degree 3,
+1024x1024, fp32, seeded synthetic scene of SURVEY.md §8(d) (S-uniform).  For N > 1 every rank renders its own view of the
+same replica (weak scaling).
 
-Rank 0 prints ONE JSON line: frames/s (whole job), the roofline of the dominant kernel (HIP events recorded on the
-launch stream inside the timed region) and a CPU baseline (the C oracle of the same workload on the host cores, plus
-the reference's CPU LBS+project path restated in C).
+Rank 0 prints ONE JSON line: frames/s (whole job), median / p10 / p90 of the per-step times, the roofline of the dominant
+kernel (HIP events recorded on the launch stream inside the timed region) against the HBM peak AND against the VALU issue
+rate that actually bounds it, the forward-only figure, the other single-GPU configs (C2, C5) as `extra`, and a CPU baseline
+(the C oracle of the same workload on the host cores, plus the reference's CPU LBS+project path restated in C).
 """
 import argparse
 import json
@@ -21,13 +28,15 @@ import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); measured copy ceiling is ~6300
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); measured copy ceiling is ~6300
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+# ns per wave64 v_fma_f32 per SIMD with 8 waves per SIMD, measured on MI355X (tools/ubench/valu_rate.hip,
+# profiles/r2_ubench_valu_rate.txt): the cheapest VALU instruction; v_pk_fma_f32 costs twice that (no gain per float)
+VALU_FMA_NS = 1.08
 
 WORKLOADS = {
     "C2": dict(P=50_000, W=512, H=512, deg=0, backward=False, desc="50k Gaussians, SH0, 512x512, forward only"),
@@ -37,13 +46,16 @@ WORKLOADS = {
 }
 
 
-def stage_bytes(P, R, HW, M, backward=True):
+def stage_bytes(P, R_ref, R_walked, HW, M, backward=True):
     """Algorithmic (compulsory) bytes per stage, SURVEY.md §8(d): every array counted once per stage that must
     produce or consume it, the sort as one read + one write of its 12-byte pairs, atomics as one write of the
-    final per-Gaussian gradient."""
-    b = dict(preprocess_fwd=P * (119 + 12 * M), scan=P * 8, binning=P * 20 + R * 44, blend_fwd=R * 44 + HW * 28)
+    final per-Gaussian gradient.  R_ref = the reference's instance count (sum of tiles_touched); R_walked = the
+    instances the binning back-end keeps and the blend kernels walk (after the exact tile culling): the binning and
+    blend terms use R_walked."""
+    del R_ref
+    b = dict(preprocess_fwd=P * (119 + 12 * M), scan=P * 8, binning=P * 20 + R_walked * 44, blend_fwd=R_walked * 44 + HW * 28)
     if backward:
-        b.update(blend_bwd=R * 44 + HW * 28 + P * 44, preprocess_bwd=P * (175 + 24 * M))
+        b.update(blend_bwd=R_walked * 44 + HW * 28 + P * 44, preprocess_bwd=P * (175 + 24 * M))
     return b
 
 
@@ -102,28 +114,131 @@ def cpu_baseline(wl, cam, g, gt, mask, bg):
                 host_cpus=os.cpu_count())
 
 
-PMC_KERNEL = {"blend_bwd": "blend_backward_kernel<1, 0, 0>", "blend_fwd": "blend_forward_kernel<1, 0>"}
+def pmc_summary(stage, workload):
+    """Counter figures per launch of the dominant kernel.  PMC passes cannot run inside the bench, so they come from the newest
+    committed summary profiles/*_pmc.csv (tools/profile_round.sh: separate rocprofv3 --pmc passes of THIS command for
+    FETCH_SIZE, WRITE_SIZE and the SQ counters; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md) -- C3 only."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))  # r1d < r2a < ...: the newest round last
+    prefix = {"blend_bwd": "blend_backward_kernel<", "blend_fwd": "blend_forward_kernel<"}.get(stage)
+    if workload != "C3" or not files or prefix is None:
+        return None
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].startswith(prefix):
+            out = {"source": "profiles/" + os.path.basename(files[-1]), "kernel": r["kernel"],
+                   "traffic": int(float(r["fetch_bytes_x2"]) + float(r["write_bytes"]))}
+            for k_csv, k in (("SQ_INSTS_VALU_per_launch", "valu_insts"), ("SQ_ACTIVE_INST_VALU_per_launch", "active_inst_valu_quads"),
+                             ("SQ_BUSY_CYCLES_per_launch", "sq_busy_cycles"), ("avg_us_under_pmc", "avg_us_under_pmc")):
+                try:
+                    out[k] = float(r[k_csv])
+                except (KeyError, ValueError):
+                    pass
+            return out
+    return None
 
 
-def list_stats(session, P, W, H):
-    """Per-tile list statistics of the last frame: instances kept after the exact tile culling, mean list
-    length over non-empty tiles, fraction of pixels whose blend stopped early (transmittance cut-off before the end of the list)."""
-    from mygauhuman_amd.diff_gaussian_rasterization import _C
-    q = lambda what: _C.query_state(what, P, session.capacity, W, H, session.geom, session.bin, session.img)  # noqa: E731
-    ranges = q("RANGES").long()
-    lens = ranges[:, 1] - ranges[:, 0]
-    gx = (W + 15) // 16
-    ncon, T = q("N_CONTRIB").long(), q("FINAL_T")
-    ys, xs = torch.meshgrid(torch.arange(H, device=T.device), torch.arange(W, device=T.device), indexing="ij")
-    tile_len = lens[(ys // 16) * gx + xs // 16]
-    early = (ncon < tile_len) & (T < 1e-3)
-    ne = lens > 0
-    return {"instances_after_tile_cull": int(lens.sum()), "mean_list_length": round(float(lens[ne].float().mean()), 1) if bool(ne.any()) else 0.0,
-            "max_list_length": int(lens.max()), "pixels_stopped_early_frac": round(float(early.float().mean()), 4)}
+class Scene:
+    """Device-resident inputs of one workload + the sync-free session(s) that render it."""
+
+    def __init__(self, name, rank, world, dev):
+        import torch
+
+        from mygauhuman_amd import cameras, parallel, synthetic
+        from mygauhuman_amd.fastpath import RasterSession
+        self.name, self.wl = name, WORKLOADS[name]
+        wl = self.wl
+        self.P, self.W, self.H, self.deg = wl["P"], wl["W"], wl["H"], wl["deg"]
+        self.M = (self.deg + 1) ** 2
+        self.g = synthetic.uniform_gaussians(self.P, seed=0, sh_degree=self.deg, log_scale_mean=wl.get("log_scale", math.log(0.01)))
+        self.gt, self.mask = synthetic.loss_targets(self.W, self.H, seed=0)
+        # one view per rank: yaw the S-uniform camera about the scene centre (a 1-GPU run = the identity view)
+        yaw = (rank - (world - 1) / 2.0) * 3.0
+        self.cam = cameras.orbit_camera(self.W, self.H, yaw) if world > 1 else cameras.make_camera(self.W, self.H, 50.0)
+        self.bg_np = np.zeros(3, np.float32)
+        to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+        g = self.g
+        self.params = dict(means3D=to(g["means3D"]), shs=to(g["shs"]), opacities=to(g["opacities"]), scales=to(g["scales"]),
+                           rotations=to(g["rotations"]))
+        if wl.get("sh_half"):
+            self.params["shs"] = self.params["shs"].half()  # fp16 SH storage (BASELINE configs[4]); gradients stay fp32
+        self.camd = dict(self.cam, viewmatrix=to(self.cam["viewmatrix"]), projmatrix=to(self.cam["projmatrix"]),
+                         campos=to(self.cam["campos"]))
+        self.bg, self.gt_d, self.mask_d = to(self.bg_np), to(self.gt), to(self.mask)
+        self.world = world
+        self.step = parallel.ViewParallelStep(self.params, self.deg, self.camd, self.bg) if wl["backward"] else None
+        self.fsession = (RasterSession.calibrated(self.params, self.camd, self.bg, self.deg, with_backward=False)
+                         if self.step is None else None)
+
+    @property
+    def session(self):
+        return self.step.session if self.step is not None else self.fsession
+
+    def one_step(self):
+        if self.step is not None:
+            self.step(self.camd, self.bg, self.gt_d, self.mask_d, reduce=self.world > 1)
+        else:
+            self.fsession.forward(self.params, self.camd, self.bg, self.deg)
+
+    def forward_only(self):
+        self.session.forward(self.params, self.camd, self.bg, self.deg)
+
+    def check(self):
+        if self.step is not None:
+            self.step.check()  # raises BinningOverflow for any overflowed step
+        if self.session.overflowed():
+            raise SystemExit("binning capacity overflow during the timed region: results invalid")
+
+    def list_stats(self):
+        """Per-tile list statistics of the last frame: instances kept after the exact tile culling, mean list
+        length over non-empty tiles, fraction of pixels whose blend stopped early (transmittance cut-off before the list end)."""
+        import torch
+
+        from mygauhuman_amd.diff_gaussian_rasterization import _C
+        s, P, W, H = self.session, self.P, self.W, self.H
+        q = lambda what: _C.query_state(what, P, s.capacity, W, H, s.geom, s.bin, s.img)  # noqa: E731
+        ranges = q("RANGES").long()
+        lens = ranges[:, 1] - ranges[:, 0]
+        gx = (W + 15) // 16
+        ncon, T = q("N_CONTRIB").long(), q("FINAL_T")
+        ys, xs = torch.meshgrid(torch.arange(H, device=T.device), torch.arange(W, device=T.device), indexing="ij")
+        tile_len = lens[(ys // 16) * gx + xs // 16]
+        early = (ncon < tile_len) & (T < 1e-3)
+        ne = lens > 0
+        return {"instances_reference": int(s.num_rendered()), "instances_after_tile_cull": int(lens.sum()),
+                "mean_list_length": round(float(lens[ne].float().mean()), 1) if bool(ne.any()) else 0.0,
+                "max_list_length": int(lens.max()), "pixels_stopped_early_frac": round(float(early.float().mean()), 4)}
+
+
+def timed(fn, steps, sync, per_step_events=True):
+    """EXACTLY `steps` calls of fn bracketed by sync() on both sides; returns (elapsed seconds, per-step ms from events)."""
+    import torch
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step_events else []
+    sync()
+    t0 = time.perf_counter()
+    if per_step_events:
+        evs[0].record()
+    for i in range(steps):
+        fn()
+        if per_step_events:
+            evs[i + 1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)] if per_step_events else []
+    return elapsed, per
+
+
+def pct(xs):
+    if not xs:
+        return None
+    a = np.asarray(xs, np.float64)
+    return {"median_ms": round(float(np.median(a)), 4), "p10_ms": round(float(np.percentile(a, 10)), 4),
+            "p90_ms": round(float(np.percentile(a, 90)), 4)}
 
 
 def measured_copy_gbs(dev):
     """Stream-copy ceiling of this GPU (read + write bytes per second of a 1 GiB device-to-device copy), SURVEY.md §8(d)."""
+    import torch
     n = 1 << 28
     a = torch.empty(n, dtype=torch.float32, device=dev)
     b = torch.empty_like(a)
@@ -138,28 +253,28 @@ def measured_copy_gbs(dev):
     return round(5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
-def pmc_traffic(stage, workload):
-    """Memory-side bytes per launch of the dominant kernel.  PMC passes cannot run inside the bench, so the figure comes from
-    the newest committed summary profiles/*_pmc.csv (tools/profile_round.sh: separate rocprofv3 --pmc passes of THIS command
-    for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled, the gfx950 correction of MI355X_MICROARCH.md) -- C3 only; else null."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))
-    if workload != "C3" or not files or stage not in PMC_KERNEL:
-        return {"traffic": None}
-    for r in csv.DictReader(open(files[-1])):
-        if r["kernel"] == PMC_KERNEL[stage]:
-            extra = {}
-            try:  # vector-ALU occupancy of the kernel: SQ_ACTIVE_INST_VALU counts quad-cycles over all SIMDs, SQ_BUSY_CYCLES
-                # cycles summed over the 32 shader engines -> busy SIMD-cycles / (kernel cycles x 1024 SIMDs)
-                busy = 4.0 * float(r["SQ_ACTIVE_INST_VALU_per_launch"]) / (float(r["SQ_BUSY_CYCLES_per_launch"]) / 32.0 * 1024.0)
-                extra = {"valu_busy_frac_pmc": round(min(busy, 1.0), 3)}
-            except (KeyError, ZeroDivisionError, ValueError):
-                pass
-            return {**extra, "traffic": int(float(r["fetch_bytes_x2"]) + float(r["write_bytes"])),
-                    "traffic_source": "profiles/" + os.path.basename(files[-1]) + " (2 x FETCH_SIZE + WRITE_SIZE per launch; "
-                                      "WRITE_SIZE counts every float-atomic lane as 4 B)"}
-    return {"traffic": None}
+def extra_workload(name, dev, steps=60, warmup=5):
+    """A secondary single-GPU config (C2 / C5) for the `extra` block of the line: frames/s from the same timed-loop protocol."""
+    import torch
+    sc = Scene(name, 0, 1, dev)
+    for _ in range(warmup):
+        sc.one_step()
+    elapsed, per = timed(sc.one_step, steps, torch.cuda.synchronize)
+    sc.check()
+    ls = sc.list_stats()
+    return {"workload": f"{name}: {sc.wl['desc']}", "value": round(steps / elapsed, 2), "unit": "frames/s",
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "dtype": "f32" if not sc.wl.get("sh_half") else "f32 (SH stored f16)",
+            "step_ms": pct(per), "instances_reference": ls["instances_reference"],
+            "instances_after_tile_cull": ls["instances_after_tile_cull"]}
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script and return their status.
+    Runs before anything has touched the GPU (no HIP call, no libgsr.so): the parent only waits."""
+    from mygauhuman_amd.launch import spawn_ranks
+    codes = spawn_ranks([sys.executable, os.path.abspath(__file__)] + argv, a.gpus)
+    bad = [c for c in codes if c != 0]
+    return bad[0] if bad else 0
 
 
 def main():
@@ -169,57 +284,33 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the forward-only / C2 / C5 figures")
     ap.add_argument("--binning", type=int, default=-1, help="0 global radix, 1 tile bucket (default: library default)")
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knob (gsr_set_tuning), repeatable")
     a = ap.parse_args()
 
-    from mygauhuman_amd import _lib, cameras, parallel, synthetic
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
+
+    from mygauhuman_amd import _lib, cameras, parallel
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     rank, world, local = parallel.init_distributed("cuda")
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rehearsal = world > 1 and os.environ.get("GSR_SINGLE_DEVICE") == "1"
     if a.binning >= 0:
         _lib.check(_lib.lib.gsr_set_binning_mode(a.binning), "gsr_set_binning_mode")
     for kv in a.tune:
         k, v = kv.split("=")
         _lib.set_tuning(k, int(v))
 
-    wl = WORKLOADS[a.workload]
-    P, W, H, deg = wl["P"], wl["W"], wl["H"], wl["deg"]
-    M = (deg + 1) ** 2
-    g = synthetic.uniform_gaussians(P, seed=0, sh_degree=deg, log_scale_mean=wl.get("log_scale", math.log(0.01)))
-    gt, mask = synthetic.loss_targets(W, H, seed=0)
-    # one view per rank: yaw the S-uniform camera about the scene centre (rank 0 of a 1-GPU run = identity view)
-    yaw = (rank - (world - 1) / 2.0) * 3.0
-    cam = cameras.orbit_camera(W, H, yaw) if world > 1 else cameras.make_camera(W, H, 50.0)
-    bg_np = np.zeros(3, np.float32)
-
-    to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
-    params = dict(means3D=to(g["means3D"]), shs=to(g["shs"]), opacities=to(g["opacities"]), scales=to(g["scales"]),
-                  rotations=to(g["rotations"]))
-    if wl.get("sh_half"):
-        params["shs"] = params["shs"].half()  # fp16 SH storage (BASELINE configs[4]); gradients stay fp32
-    camd = dict(cam, viewmatrix=to(cam["viewmatrix"]), projmatrix=to(cam["projmatrix"]), campos=to(cam["campos"]))
-    bg, gt_d, mask_d = to(bg_np), to(gt), to(mask)
-    step = parallel.ViewParallelStep(params, deg, camd, bg) if wl["backward"] else None
-    from mygauhuman_amd.diff_gaussian_rasterization import _C
-    e = torch.empty(0)
-
-    def fwd_only():
-        return _C.rasterize_gaussians(bg, params["means3D"], e, params["opacities"], params["scales"], params["rotations"],
-                                      1.0, e, camd["viewmatrix"], camd["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W,
-                                      params["shs"], deg, camd["campos"], False, False)
-
-    from mygauhuman_amd.fastpath import RasterSession
-    fsession = None if wl["backward"] else RasterSession.calibrated(params, camd, bg, deg, with_backward=False)
-
-    def one_step():
-        if wl["backward"]:
-            step(camd, bg, gt_d, mask_d, reduce=world > 1)
-        else:
-            fsession.forward(params, camd, bg, deg)  # sync-free session, like the fwd+bwd workloads
+    sc = Scene(a.workload, rank, world, dev)
+    wl, P, W, H, M = sc.wl, sc.P, sc.W, sc.H, sc.M
 
     def sync():
         if world > 1:
@@ -228,70 +319,115 @@ def main():
 
     # ---- untimed: warm-up, then a pass with every stage bracketed by events to find the dominant kernel
     for _ in range(max(1, a.warmup)):
-        one_step()
+        sc.one_step()
     sync()
-    R = step.session.num_rendered() if step is not None else fwd_only()[0]
     _lib.profile_enable(_lib.PROF_STAGES)
     for _ in range(5):
-        one_step()
+        sc.one_step()
     torch.cuda.synchronize()
     prof = _lib.profile_read()
     stage_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items()}
     dominant = max(stage_ms, key=stage_ms.get)
     _lib.profile_enable([dominant])  # only the dominant kernel keeps its two event records in the timed region
 
-    # ---- timed region
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
+    elapsed, per_step = timed(sc.one_step, a.steps, sync)
+    ls = sc.list_stats()  # (synchronises; after the timed region)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    Rt = torch.tensor([float(R)], dtype=torch.float64, device=dev)
+    Rt = torch.tensor([float(ls["instances_after_tile_cull"])], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(Rt, op=dist.ReduceOp.SUM)
+        parallel.all_reduce_(t, dist.ReduceOp.MAX)
+        parallel.all_reduce_(Rt, dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    if (step is not None and step.session.overflowed()) or (fsession is not None and fsession.overflowed()):
-        raise SystemExit("binning capacity overflow during the timed region: results invalid")
+    sc.check()
     dom_ms, dom_n = _lib.profile_read()[dominant]
     _lib.profile_enable([])
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         fps = world * a.steps / elapsed
-        sb = stage_bytes(P, R, W * H, M, wl["backward"])
+        R_ref, R_walked = ls["instances_reference"], ls["instances_after_tile_cull"]
+        sb = stage_bytes(P, R_ref, R_walked, W * H, M, wl["backward"])
+        sb_ref = stage_bytes(P, R_ref, R_ref, W * H, M, wl["backward"])
         dom_avg_ms = dom_ms / max(dom_n, 1)
         achieved = sb[dominant] / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
         frame_bytes = sum(sb.values())
+        pmc = pmc_summary(dominant, a.workload)
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc["traffic"] if pmc else None,
+                "algorithmic_bytes_per_launch": int(sb[dominant]), "algorithmic_bytes_per_launch_reference_R": int(sb_ref[dominant]),
+                "avg_launch_ms": round(dom_avg_ms, 5), "launches_timed": int(dom_n)}
+        if pmc:
+            roof["traffic_source"] = pmc["source"] + " (2 x FETCH_SIZE + WRITE_SIZE per launch; WRITE_SIZE counts every float-atomic lane as 4 B)"
+        if pmc and "valu_insts" in pmc and dom_avg_ms > 0:
+            # The blend kernels are bound by vector-instruction ISSUE, not by HBM.  Issue roofline of the kernel as it is:
+            # every wave64 VALU instruction holds its SIMD for at least the time of an FMA (VALU_FMA_NS, measured); a kernel made
+            # of the same number of instructions cannot run faster than  insts x VALU_FMA_NS / 1024 SIMDs.  frac = that floor /
+            # the measured launch time; ns_per_inst = what an instruction really costs here (exp / rcp 3.3x, DPP and permlane
+            # swaps 4x, compare+select 1.7x an FMA: profiles/r2_ubench_valu_rate.txt).
+            n_i = pmc["valu_insts"]
+            floor_ms = n_i * VALU_FMA_NS / N_SIMD * 1e-6
+            roof["valu_issue"] = {
+                "bound": "valu_issue", "valu_insts_per_launch": int(n_i), "fma_ns_per_inst_per_simd": VALU_FMA_NS,
+                "floor_ms_if_all_fma": round(floor_ms, 5), "frac": round(floor_ms / dom_avg_ms, 4),
+                "ns_per_inst_per_simd": round(dom_avg_ms * 1e6 * N_SIMD / n_i, 3),
+                "insts_per_walked_instance": round(n_i / max(R_walked, 1), 1), "source": pmc["source"]}
+            if "active_inst_valu_quads" in pmc and pmc.get("avg_us_under_pmc"):
+                # busy fraction straight from the counters, unclamped: SQ_ACTIVE_INST_VALU (quad-cycles summed over all SIMDs) x 4
+                # over 1024 SIMDs x the kernel's cycles at the clock implied by SQ_BUSY_CYCLES (summed over 32 shader engines)
+                cyc = pmc["sq_busy_cycles"] / 32.0
+                roof["valu_issue"]["valu_busy_frac_pmc"] = round(4.0 * pmc["active_inst_valu_quads"] / (cyc * N_SIMD), 3)
+                roof["valu_issue"]["clock_ghz_pmc"] = round(cyc / (pmc["avg_us_under_pmc"] * 1e3), 3)
         out = {
             "metric": "frames/sec fwd+bwd @1024^2, 200k Gaussians" if a.workload == "C3" else f"frames/sec {wl['desc']}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {wl['desc']}; S-uniform seed 0, FoV 50deg, "
-                                   + ("identity camera" if world == 1 else f"{world} views/step, 1 view/GPU (cameras orbiting the scene centre in 3deg steps), RCCL all-reduce of "
-                                      f"{(step.bucket.nbytes if step else 0) / 1e6:.1f} MB gradients"
-                                      + (f" + all-gather of {step.compact.stride * 4 / 1e6:.1f} MB/rank (compact SH gradient)"
-                                         if (step is not None and step.compact is not None) else "")),
-                       "P": P, "sh_degree": deg, "width": W, "height": H, "num_rendered_rank0": int(R),
+                                   + ("identity camera" if world == 1 else
+                                      f"{world} views/step, 1 view/rank (cameras orbiting the scene centre in 3deg steps), "
+                                      + ("REHEARSAL: all ranks on ONE device over gloo with host-staged collectives -- functional "
+                                         "check of the view-parallel path, not a scaling number; " if rehearsal else "RCCL ")
+                                      + f"all-reduce of {sc.step.bucket.nbytes / 1e6:.1f} MB gradients"
+                                      + (f" + all-gather of {sc.step.compact.stride * 4 / 1e6:.1f} MB/rank (compact SH gradient)"
+                                         if (sc.step is not None and sc.step.compact is not None) else "")),
+                       "P": P, "sh_degree": sc.deg, "width": W, "height": H,
+                       "instances_reference_rank0": int(R_ref), "instances_after_tile_cull_rank0": int(R_walked),
                        "binning": "tile_bucket" if _lib.lib.gsr_get_binning_mode() == 1 else "global_radix",
-                       "host_sync_per_step": 0},
+                       "host_sync_per_step": 0, "backend": (dist.get_backend() if world > 1 else None)},
+            "step_ms": pct(per_step),
             "splatted_gaussians_per_s": round(fps * P, 1),
             "instances_per_s": round(float(Rt.item()) * a.steps / elapsed, 1),
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic(dominant, a.workload),
-                         "algorithmic_bytes_per_launch": int(sb[dominant]), "avg_launch_ms": round(dom_avg_ms, 5),
-                         "launches_timed": int(dom_n)},
+            "roofline": roof,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items() if k in sb},
-            "frame_algorithmic_bytes": int(frame_bytes),
+            "stage_algorithmic_gbs": {k: round(sb[k] / (stage_ms[k] * 1e-3) / 1e9, 1) for k in sb if stage_ms.get(k, 0) > 0},
+            "frame_algorithmic_bytes": int(frame_bytes), "frame_algorithmic_bytes_reference_R": int(sum(sb_ref.values())),
             "frame_hbm_frac": round(frame_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 5),
-            "hbm_copy_measured_gbs": measured_copy_gbs(dev),
-            "list_stats": list_stats(step.session if step is not None else fsession, P, W, H),
+            "list_stats": ls,
         }
+    # ---- untimed extras (1-GPU run only): forward-only figure of the same workload, the other single-GPU configs
+    if rank == 0 and world == 1 and not a.no_extra:
+        out["hbm_copy_measured_gbs"] = measured_copy_gbs(dev)
+        extra = {}
+        if wl["backward"]:
+            for _ in range(3):
+                sc.forward_only()
+            el, per = timed(sc.forward_only, a.steps, torch.cuda.synchronize)
+            extra["forward_only"] = {"workload": f"{a.workload} forward only", "value": round(a.steps / el, 2), "unit": "frames/s",
+                                     "ms_per_step": round(el / a.steps * 1e3, 4), "step_ms": pct(per)}
+        del sc
+        torch.cuda.empty_cache()
+        for name in ("C2", "C5"):
+            if name != a.workload:
+                extra[name] = extra_workload(name, dev)
+        out["extra"] = extra
+    if rank == 0:
         if not a.no_cpu_baseline and world == 1:  # the CPU baseline is reported by the 1-GPU run only
-            out["cpu_baseline"] = cpu_baseline(wl, cameras.make_camera(W, H, 50.0), g, gt, mask, bg_np)
+            from mygauhuman_amd import synthetic
+            g = synthetic.uniform_gaussians(P, seed=0, sh_degree=wl["deg"], log_scale_mean=wl.get("log_scale", math.log(0.01)))
+            gt, mask = synthetic.loss_targets(W, H, seed=0)
+            out["cpu_baseline"] = cpu_baseline(wl, cameras.make_camera(W, H, 50.0), g, gt, mask, np.zeros(3, np.float32))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

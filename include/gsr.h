@@ -297,10 +297,23 @@ int gsr_knn_nearest(int M, const float *query, int N, const float *ref, int *idx
  *   gsr_sh_view_pack: packed[P][3] = dL_dcolor (the backward's dL_dcolor output of an SH-mode call) with the channels the
  *     forward clamped set to zero; geom_buffer is that call's geometry buffer.
  *   gsr_sh_grad_from_views: dL_dsh[P][M][3] = scale * sum_v w_k(normalise(means3D - campos_v)) * packed_v, v in fixed
- *     order; `views` holds n_views blocks of view_stride floats: [P*3 packed | campos xyz | padding]. */
+ *     order; `views` holds n_views blocks of view_stride floats: [P*3 packed | campos xyz | padding].  dev_scale (device
+ *     pointer to one float, or null) multiplies `scale`: the view-parallel step passes 0 there for a step some rank could not
+ *     render (binning overflow), so that every replica skips it, without a host read. */
 int gsr_sh_view_pack(int P, const char *geom_buffer, const float *dL_dcolor, float *packed, gsr_stream_t stream);
 int gsr_sh_grad_from_views(int P, int sh_degree, int M, int n_views, const float *means3D, const float *views,
-                           size_t view_stride, float scale, float *dL_dsh, gsr_stream_t stream);
+                           size_t view_stride, float scale, const float *dev_scale, float *dL_dsh, gsr_stream_t stream);
+
+/* Bookkeeping of one view-parallel step around its gradient all-reduce, one single-thread launch, no host read
+ * (extension).  status = dev_status of the step's gsr_rasterize_forward_async (R, overflow flag); overflow_slot = one float
+ * inside the all-reduced gradient bucket.
+ *   phase 0 (before the reduction): overflow_slot[0] = overflow flag as 0/1
+ *   phase 1 (after the SUM reduction): scale[0] = overflow_slot[0] > 0 ? 0 : inv_world  (a step some rank could not render
+ *            is skipped by every replica); report[0..2] = {ranks that overflowed, R, own flag} -- `report` may be pinned,
+ *            device-mapped host memory, examined by the host after an event
+ *   phase 2: both (single process). */
+int gsr_step_status(int phase, const uint32_t *status, float *overflow_slot, float inv_world, float *scale, uint32_t *report,
+                    gsr_stream_t stream);
 
 /* SMPL pose -> joint transforms (batch size 1): rodrigues of the 24 axis-angle vectors (angle = |theta + 1e-8|), the
  * optional pose-refinement product R_j <- R_j correct_Rs[j-1] (j >= 1), the kinematic chain and the removal of the rest

@@ -26,10 +26,11 @@ constexpr int XSH_LDS_ROW = 52;  // 48 floats + pad: 16-byte aligned, conflict-f
 // views: n_views blocks of `stride` floats each: [P*3 masked dL_dRGB | campos xyz | pad]
 template <bool STAGE>
 __global__ __launch_bounds__(XSH_BLOCK) void sh_grad_from_views_kernel(int P, int D, int M, int n_views, const float *means3D,
-                                                                      const float *views, size_t stride, float scale,
-                                                                      float *dL_dsh) {
+                                                                      const float *views, size_t stride, float scale_h,
+                                                                      const float *dev_scale, float *dL_dsh) {
   __shared__ __attribute__((aligned(16))) float s_out[STAGE ? XSH_BLOCK * XSH_LDS_ROW : 4];
   const int i = blockIdx.x * XSH_BLOCK + threadIdx.x;
+  const float scale = dev_scale ? scale_h * dev_scale[0] : scale_h;  // wave-uniform scalar load
   float acc[48];
 #pragma unroll
   for (int k = 0; k < 48; k++) acc[k] = 0.f;
@@ -70,9 +71,35 @@ __global__ __launch_bounds__(XSH_BLOCK) void sh_grad_from_views_kernel(int P, in
   }
 }
 
+// one thread: bookkeeping of a view-parallel step around the gradient all-reduce (see gsr_step_status in gsr.h)
+__global__ void step_status_kernel(int phase, const uint32_t *status, float *overflow_slot, float inv_world, float *scale,
+                                   uint32_t *report) {
+  if (phase == 0 || phase == 2) overflow_slot[0] = status[1] ? 1.f : 0.f;
+  if (phase == 1 || phase == 2) {
+    const float ranks = overflow_slot[0];
+    scale[0] = ranks > 0.f ? 0.f : inv_world;
+    report[0] = (uint32_t)(ranks + 0.5f);
+    report[1] = status[0];
+    report[2] = status[1];
+  }
+}
+
 }  // namespace gsr
 
 extern "C" {
+
+int gsr_step_status(int phase, const uint32_t *status, float *overflow_slot, float inv_world, float *scale, uint32_t *report,
+                    gsr_stream_t stream_) {
+  using namespace gsr;
+  if (phase < 0 || phase > 2 || !status || !overflow_slot || (phase != 0 && (!scale || !report))) {
+    set_error("gsr_step_status: bad arguments");
+    return GSR_EINVAL;
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(1), 0, stream, phase, status, overflow_slot, inv_world, scale, report);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
 
 int gsr_sh_view_pack(int P, const char *geom_buffer, const float *dL_dcolor, float *packed, gsr_stream_t stream_) {
   using namespace gsr;
@@ -89,7 +116,7 @@ int gsr_sh_view_pack(int P, const char *geom_buffer, const float *dL_dcolor, flo
 }
 
 int gsr_sh_grad_from_views(int P, int sh_degree, int M, int n_views, const float *means3D, const float *views,
-                           size_t view_stride, float scale, float *dL_dsh, gsr_stream_t stream_) {
+                           size_t view_stride, float scale, const float *dev_scale, float *dL_dsh, gsr_stream_t stream_) {
   using namespace gsr;
   if (P < 0 || sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16 || n_views < 1 ||
       view_stride < (size_t)P * 3 + 3 || (P > 0 && (!means3D || !views || !dL_dsh))) {
@@ -102,10 +129,10 @@ int gsr_sh_grad_from_views(int P, int sh_degree, int M, int n_views, const float
   const dim3 grid((P + XSH_BLOCK - 1) / XSH_BLOCK), block(XSH_BLOCK);
   if (stage)
     hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, grid, block, 0, stream, P, sh_degree, M, n_views, means3D, views,
-                       view_stride, scale, dL_dsh);
+                       view_stride, scale, dev_scale, dL_dsh);
   else
     hipLaunchKernelGGL(sh_grad_from_views_kernel<false>, grid, block, 0, stream, P, sh_degree, M, n_views, means3D, views,
-                       view_stride, scale, dL_dsh);
+                       view_stride, scale, dev_scale, dL_dsh);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
 }

@@ -45,6 +45,16 @@ class RasterSession:
         P, M = params["means3D"].shape[0], params["shs"].shape[1]
         return RasterSession(P, cam["W"], cam["H"], M, params["means3D"].device, int(R * slack) + 4096, with_backward)
 
+    def regrown(self, capacity):
+        """A session of the same shape with a larger binning capacity (the other buffers are reused)."""
+        if capacity <= self.capacity:
+            return self
+        n = RasterSession.__new__(RasterSession)
+        n.__dict__.update(self.__dict__)
+        n.capacity = int(capacity)
+        n.bin = torch.empty(lib.gsr_binning_bytes(n.capacity, n.W, n.H), dtype=torch.uint8, device=n.device)
+        return n
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 

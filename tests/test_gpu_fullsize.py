@@ -88,13 +88,32 @@ def test_c3_forward_backward_properties():
             util.set_tile_cull(_lib.DEFAULT_TILE_CULL)
         f = util.hip_forward(cam, g, bg, "sh")
         color, alpha = f["color"].cpu().numpy(), f["alpha"].cpu().numpy()
-        dc = (np.sign(color - gt) / color.size).astype(np.float32)
-        da = (0.2 * (alpha - mask) / alpha.size).astype(np.float32)
-        dd = np.zeros_like(alpha)
+        if waves == 1:
+            # the loss gradient of train.py:261-262 WITHOUT its 1 / (3 H W) normalisation: O(1) per pixel, so that the
+            # per-Gaussian gradients are O(1..100) and the relative tolerances below mean something.  Fixed for all variants.
+            dc = np.sign(color - gt).astype(np.float32)
+            da = (0.2 * (alpha - mask)).astype(np.float32)
+            dd = np.zeros_like(alpha)
         grads = util.hip_backward(f, dc, dd, da)
         outs[waves] = (f, color, alpha, grads, dc, da, dd)
     f4, c4, a4, g4, dc, da, dd = outs[4]
     assert f4["R"] > 1_000_000
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        assert float(np.abs(g4[k]).max()) > 1e-2, k  # the gradients are not vanishing: the comparisons below have teeth
+    # tight tile culling (library default, the benched path) against the reference's full lists AT C3: the images are the same
+    # bits (culled instances never blended anything) and the gradients agree to 1e-5 of the tensor scale (summation order)
+    util.set_tile_cull(False)
+    fn = util.hip_forward(cam, g, bg, "sh")
+    gn = util.hip_backward(fn, dc, dd, da)
+    util.set_tile_cull(_lib.DEFAULT_TILE_CULL)
+    rt = util.hip_query(f4, "RANGES").view(np.uint32).reshape(-1, 2).astype(np.int64)
+    rn = util.hip_query(fn, "RANGES").view(np.uint32).reshape(-1, 2).astype(np.int64)
+    assert int((rt[:, 1] - rt[:, 0]).sum()) < int((rn[:, 1] - rn[:, 0]).sum()) == fn["R"]
+    for k in ("color", "alpha", "depth"):
+        assert torch.equal(f4[k], fn[k]), f"C3 {k}: tile culling changed the image"
+    assert torch.equal(util.to_dev(util.hip_query(f4, "FINAL_T")), util.to_dev(util.hip_query(fn, "FINAL_T")))
+    for k in g4:
+        util.assert_close(f"{k} cull on/off", g4[k], gn[k], tol=1e-5, max_bad_frac=1e-5)
     for waves in (1, 2):
         f, c, a, gr = outs[waves][:4]
         # same per-pixel arithmetic up to FMA contraction choices of each template instantiation
@@ -119,7 +138,7 @@ def test_c3_forward_backward_properties():
 
 
 def test_c5_lbs_render_prune_at_500k(oracle):
-    """BASELINE configs[4] at full size (fp32 SH): 500k articulated Gaussians -> per-frame LBS + fused render() forward / backward
+    """BASELINE configs[4] at full size (fp32 SH; the fp16-SH leg is test_c5_fp16_sh_at_500k below): 500k articulated Gaussians -> per-frame LBS + fused render() forward / backward
     at 1024^2 -> k-NN based prune.  Size-independent properties: finite outputs, visible <=> radii > 0, gradients only on
     visible Gaussians, nearest-vertex distances equal to the brute-force oracle's, prune count equal to the mask count."""
     import types
@@ -156,3 +175,38 @@ def test_c5_lbs_render_prune_at_500k(oracle):
     mask = densify.densify_and_prune(model, 1e9, 0.0, 2.0, 0, t_vertices=verts)
     assert int(mask[:1000].sum()) == 1000
     assert model._xyz.shape[0] == P - int(mask.sum()) and model._features_rest.shape == (model._xyz.shape[0], 15, 3)
+
+
+def test_c5_fp16_sh_at_500k():
+    """BASELINE configs[4] storage mode at full size: 500k Gaussians, SH coefficients stored as fp16, 1024^2, forward + backward
+    through the sync-free session (what bench.py --workload C5 runs).  Property: bit-identical outputs and gradients close to
+    summation order against the fp32 path fed the SAME (fp16-rounded) coefficients."""
+    import math
+
+    from mygauhuman_amd import synthetic
+    from mygauhuman_amd.fastpath import RasterSession
+    P, W, H, deg = 500_000, 1024, 1024, 3
+    cam, g = synthetic.uniform_scene(P, W, H, seed=0, sh_degree=deg, log_scale_mean=math.log(0.005))
+    gt, mask = synthetic.loss_targets(W, H)
+    to = util.to_dev
+    half = to(g["shs"]).half()
+    base = dict(means3D=to(g["means3D"]), opacities=to(g["opacities"]), scales=to(g["scales"]), rotations=to(g["rotations"]))
+    camd = dict(cam, viewmatrix=to(cam["viewmatrix"]), projmatrix=to(cam["projmatrix"]), campos=to(cam["campos"]))
+    bg = to(np.array([0.1, 0.2, 0.3], np.float32))
+    res = {}
+    for name, shs in (("f16", half), ("f32", half.float())):
+        params = dict(base, shs=shs)
+        s = RasterSession.calibrated(params, camd, bg, deg)
+        color, depth, alpha, radii = s.forward(params, camd, bg, deg)
+        dc = torch.sign(color - to(gt)).contiguous()
+        da = (0.2 * (alpha - to(mask))).contiguous()
+        out = dict(means3D=torch.empty(P, 3, device="cuda"), sh=torch.empty(P, 16, 3, device="cuda"), opacity=torch.empty(P, 1, device="cuda"),
+                   scales=torch.empty(P, 3, device="cuda"), rotations=torch.empty(P, 4, device="cuda"))
+        s.backward(params, camd, bg, deg, dc, s.dL_ddepth, da, out)
+        assert not s.overflowed() and s.num_rendered() > 1_000_000
+        res[name] = (color.clone(), alpha.clone(), depth.clone(), radii.clone(), {k: v.cpu().numpy() for k, v in out.items()})
+    for i, k in enumerate(("color", "alpha", "depth", "radii")):
+        assert torch.equal(res["f16"][i], res["f32"][i]), k
+    for k, v in res["f16"][4].items():
+        assert np.isfinite(v).all() and float(np.abs(v).max()) > 1e-2, k
+        util.assert_close(f"C5 fp16-SH {k}", v, res["f32"][4][k], tol=1e-5, max_bad_frac=1e-5)

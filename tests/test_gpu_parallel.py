@@ -41,7 +41,7 @@ def test_compact_sh_exchange_equals_mean_of_view_gradients(deg, n_views):
     want /= n_views
     got = torch.empty((P, M, 3), device="cuda")
     _lib.check(_lib.lib.gsr_sh_grad_from_views(P, deg, M, n_views, params["means3D"].data_ptr(), gathered.data_ptr(), stride,
-                                               1.0 / n_views, got.data_ptr(), torch.cuda.current_stream().cuda_stream), "from_views")
+                                               1.0 / n_views, None, got.data_ptr(), torch.cuda.current_stream().cuda_stream), "from_views")
     torch.cuda.synchronize()
     scale = float(want.abs().max())
     assert scale > 0 and clamped_any > 0

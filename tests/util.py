@@ -68,21 +68,26 @@ def hip_backward(f, dL_dcolor, dL_ddepth, dL_dalpha, debug=False):
     return {n: o.cpu().numpy() for n, o in zip(names, out)}
 
 
-def assert_close(name, got, want, tol=1e-4, mask=None, max_bad_frac=0.0):
-    """|got - want| <= tol * max(1, |want|, scale) elementwise, where scale = the tensor's 99.9th percentile magnitude
-    (sums of many +/- terms are accurate relative to the terms, not to the possibly cancelled result)."""
+def assert_close(name, got, want, tol=1e-4, mask=None, max_bad_frac=0.0, atol=0.0):
+    """|got - want| <= tol * max(|want|, scale) + atol elementwise, where scale = the tensor's OWN 99.9th percentile
+    magnitude (sums of many +/- terms are accurate relative to the terms, not to the possibly cancelled result).  There is no
+    built-in absolute floor: a tensor of tiny gradients is held to tol relative to its own size (pass atol where an
+    absolute floor is meant)."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, (name, got.shape, want.shape)
     if got.size == 0:
         return
-    scale = max(1.0, float(np.percentile(np.abs(want), 99.9)))
+    scale = float(np.percentile(np.abs(want), 99.9))
+    if scale == 0.0:
+        scale = float(np.abs(want).max())
     err = np.abs(got - want)
-    bound = tol * np.maximum(np.abs(want), scale)
+    bound = tol * np.maximum(np.abs(want), scale) + atol
     bad = err > bound
     if mask is not None:
         bad &= mask
     frac = bad.mean()
-    assert frac <= max_bad_frac, f"{name}: {bad.sum()} / {bad.size} elements off; max err {err[bad].max():.3e} (scale {scale:.3e})"
+    assert frac <= max_bad_frac, (f"{name}: {bad.sum()} / {bad.size} elements off; max err {err[bad].max():.3e} "
+                                  f"(scale {scale:.3e}, tol {tol:g}, atol {atol:g})")
 
 
 def set_tile_cull(on):

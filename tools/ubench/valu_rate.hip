@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DPPADD(v, ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
 
 template <int KIND>
@@ -47,6 +48,28 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
           asm volatile("" : "+v"(t));
           x[i] = x[(i + 1) & 7] + t;
         }
+        if (KIND == 13) {  // packed f32 FMA: two floats per lane per instruction (v_pk_fma_f32)
+          if (i % 2 == 0) {
+            f32x2 v = {x[i], x[i + 1]};
+            const f32x2 av = {a, a}, bv = {b, b};
+            v = __builtin_elementwise_fma(v, av, bv);
+            x[i] = v.x;
+            x[i + 1] = v.y;
+          }
+        }
+        if (KIND == 14) {  // packed f32 multiply + add (v_pk_mul_f32, v_pk_add_f32)
+          if (i % 2 == 0) {
+            f32x2 v = {x[i], x[i + 1]};
+            const f32x2 av = {a, a}, bv = {b, b};
+            v = v * av;
+            asm volatile("" : "+v"(v));
+            v = v + bv;
+            x[i] = v.x;
+            x[i + 1] = v.y;
+          }
+        }
+        if (KIND == 15) x[i] = __builtin_amdgcn_rcpf(x[i]);
+        if (KIND == 16) x[i] = fminf(x[i] * a, b);   // v_mul + v_min
         if (KIND == 10) x[i] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[i]), 0xB1, 0xF, 0xF, false)) ;  // mov_dpp only
       }
     }
@@ -64,7 +87,7 @@ void run(const char *name, int instr_per_iter) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  for (int wps : {2, 8}) {  // waves per SIMD
+  for (int wps : {1, 2, 4, 8}) {  // waves per SIMD
     const int blocks = 256 * wps;  // 256 CUs x (wps blocks of 4 waves)
     const int iters = 2000;
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 10, 1.0001f, 0.5f);
@@ -94,5 +117,9 @@ int main() {
   run<10>("v_mov_dpp only", 64);
   run<11>("mov_dpp ; add (unfused)", 64);
   run<12>("mov_dpp ; add other reg", 64);
+  run<13>("v_pk_fma_f32 (per 2 floats)", 32);
+  run<14>("v_pk_mul + v_pk_add (per 2)", 32);
+  run<15>("v_rcp_f32", 64);
+  run<16>("v_mul + v_min", 64);
   return 0;
 }
