@@ -60,12 +60,22 @@ const char *gsr_last_error(void);
 int gsr_set_binning_mode(int mode);
 int gsr_get_binning_mode(void);
 
-/* Performance knobs (images, radii and gradients never change):
+/* Knobs (images, radii and gradients never change beyond summation order):
+ *   "binning_mode" (= gsr_set_binning_mode);
  *   "blend_fwd_waves" / "blend_bwd_waves" in {1, 2, 4}: waves that cooperate on one 16x16 tile (a lane owns 4 / waves pixels);
- *   "blend_bwd_reduce" in {0, 1}: cross-lane reduction of the backward on the VALU (DPP / permlane, default) or through MFMA;
+ *   "blend_bwd_reduce" in {0, 1, 2}: cross-lane reduction of the backward: DPP / permlane on the VALU (default), MFMA on the
+ *       folded rows, or the transposed MFMA contraction (documented experiments: slower on gfx950);
  *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the tile-bucket back-end;
- *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above). */
+ *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above);
+ *   "deterministic" in {0, 1}: the backward reduces its per-(Gaussian, tile-quadrant) partial sums in a fixed order instead of
+ *       with float atomics: run-to-run bit-identical gradients (for tests; costs a 256-byte slot per instance quadrant).
+ * gsr_set_tuning sets the PROCESS DEFAULTS.  gsr_set_stream_tuning gives one stream its own set (initialised from the
+ * defaults at its first call); every API call resolves its knobs once, at entry, from the stream it is given, so calls on
+ * different streams are independent of each other whatever threads they come from (no mutable global state is consulted
+ * below the API layer).  gsr_clear_stream_tuning returns a stream to the defaults. */
 int gsr_set_tuning(const char *key, int value);
+int gsr_set_stream_tuning(gsr_stream_t stream, const char *key, int value);
+int gsr_clear_stream_tuning(gsr_stream_t stream);
 
 /* Optional stage timing with HIP events recorded on the caller's stream around the selected stages' kernels
  * (no synchronisation until gsr_profile_read).  Stage ids: 0 forward preprocess, 1 scan, 2 binning (duplicate+sort+
@@ -100,8 +110,10 @@ int gsr_rasterize_forward(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_
  * call, CR/rasterizer_impl.cu:283).  The caller owns the three scratch buffers (gsr_geometry_bytes(P),
  * gsr_binning_bytes(capacity, w, h), gsr_image_bytes(w, h)) and picks `binning_capacity` = the number of
  * (Gaussian, tile) instances the binning buffer can hold; nothing is read back and the host never waits.
- * dev_status is device uint32[2]: [0] = R, [1] = 1 if R > capacity, in which case NOTHING was rendered (outputs hold
- * the background) and the call must be repeated with a larger capacity.  Always uses the tile-bucket binning.
+ * dev_status is device uint32[2]: [0] = R, [1] = flags: bit 0 = R > capacity, in which case NOTHING was rendered (outputs
+ * hold the background) and the call must be repeated with a larger capacity; bit 1 = a point was filtered although
+ * `prefiltered` was set (the reference traps the device there, CR/auxiliary.h:156-160; here the point is culled and the call is
+ * flagged -- the blocking entry points return GSR_EINVAL with the reference's message).  Always uses the tile-bucket binning.
  * The matching backward is gsr_rasterize_backward with R = binning_capacity. */
 size_t gsr_geometry_bytes(int P);
 size_t gsr_image_bytes(int width, int height);

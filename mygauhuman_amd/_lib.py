@@ -16,7 +16,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 # every symbol include/gsr.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read",
+    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
@@ -52,6 +52,9 @@ def _load():
     lib.gsr_set_binning_mode.argtypes = [C.c_int]
     lib.gsr_get_binning_mode.restype = C.c_int
     lib.gsr_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.gsr_set_stream_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.gsr_clear_stream_tuning.argtypes = [C.c_void_p]
+    lib.gsr_set_stream_tuning.restype = lib.gsr_clear_stream_tuning.restype = C.c_int
     lib.gsr_profile_enable.argtypes = [C.c_uint]
     lib.gsr_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.gsr_mark_visible.argtypes = [C.c_int, fp, fp, fp, vp, vp]
@@ -163,5 +166,13 @@ def profile_read():
     return out
 
 
-def set_tuning(key, value):
-    check(lib.gsr_set_tuning(key.encode(), int(value)), "gsr_set_tuning")
+def set_tuning(key, value, stream=None):
+    """Process default of a knob, or (stream = a torch.cuda.Stream / raw handle) that stream's own value."""
+    if stream is None:
+        check(lib.gsr_set_tuning(key.encode(), int(value)), "gsr_set_tuning")
+    else:
+        check(lib.gsr_set_stream_tuning(getattr(stream, "cuda_stream", stream), key.encode(), int(value)), "gsr_set_stream_tuning")
+
+
+def clear_stream_tuning(stream):
+    check(lib.gsr_clear_stream_tuning(getattr(stream, "cuda_stream", stream)), "gsr_clear_stream_tuning")

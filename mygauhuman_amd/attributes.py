@@ -3,41 +3,14 @@ in the posed frame, the view-dependent colour and the six feature colour sets (n
 roughness, minimum axis).
 
     frame_attributes(...)        one HIP kernel forward + one backward (csrc/attributes.hip); tensors must live on the GPU
-    frame_attributes_torch(...)  the reference's chain of torch ops, written bmm-free -- the fp32 reference the parity
-                                 tests compare the kernel with, and what render() runs with pipe.torch_attributes=True
-Both return (cov3D [P,6], colors [P,3] or None, features [P,18]) with
+(the chain of torch ops it replaces is kept with the tests as its checker: tests/torch_reference.py).
+Returns (cov3D [P,6], colors [P,3] or None, features [P,18]) with
 features = cat(normal, world_normal, albedo, occlusion, roughness.mean x3, axis) -- the `extra` operand of
 diff_gaussian_rasterization.rasterize_gaussians_multi.
 """
 import torch
 
-from . import covariance
 from ._lib import check, lib, ptr
-from .sh_utils import eval_sh
-
-
-def _view_colour(v, viewmatrix):
-    t = covariance.transformVector3x3(v, viewmatrix)
-    return torch.stack([t[:, 0], -t[:, 1], t[:, 2]], dim=1) * 0.5 + 0.5  # regularise to the gt normal space (:167)
-
-
-def frame_attributes_torch(means3D, transforms, world_normals, scales, scale_modifier, rot_cov, rot_axis, albedo, roughness,
-                           occlusion, shs, sh_degree, campos, viewmatrix):
-    dir_pp = means3D - campos.reshape(1, 3)
-    dirn = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-    axis, _ = covariance.flip_align_view(covariance.get_minimum_axis(scales, rot_axis), dirn)
-    axis = axis / axis.norm(dim=1, keepdim=True)
-    world_axis = covariance.bmm3(transforms, axis[..., None]).squeeze(-1)
-    world_axis = world_axis / world_axis.norm(dim=1, keepdim=True)
-    wn = world_normals / world_normals.norm(dim=1, keepdim=True)
-    cov3D = covariance.build_covariance_from_scaling_rotation(scales, scale_modifier, rot_cov, transforms)
-    colors = None
-    if shs is not None:
-        colors = torch.clamp_min(eval_sh(sh_degree, shs.transpose(1, 2), dirn) + 0.5, 0.0)
-    rough3 = roughness.mean(dim=1)[:, None].repeat(1, 3)
-    features = torch.cat([_view_colour(wn, viewmatrix), wn * 0.5 + 0.5, albedo, occlusion, rough3,
-                          _view_colour(world_axis, viewmatrix)], dim=1)
-    return cov3D, colors, features
 
 
 class _FrameAttributes(torch.autograd.Function):

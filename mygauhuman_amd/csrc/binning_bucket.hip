@@ -28,28 +28,11 @@ constexpr int SORT_BIG = 8192;  // LDS capacity (keys) of the workgroup sort use
 // rank[instance] so that the scatter pass needs no second round of atomics.  Counter t lives at counts[t * CSTRIDE]:
 // device-scope atomics execute at the memory side and serialise per 64-byte line, so neighbouring tiles should not
 // share a line.
-static int g_cstride = 4;  // interleaved A/B on MI355X at C3, us of binning: 1: 112, 2: 106, 4: 100, 16: 126
-int set_bucket_counter_stride(int s) {
-  if (s != 1 && s != 2 && s != 4 && s != 8 && s != 16) {
-    set_error("bucket_cstride must be 1, 2, 4, 8 or 16");
-    return GSR_EINVAL;
-  }
-  g_cstride = s;
-  return GSR_OK;
-}
-// Tight tile culling (tuning knob "tile_cull", default on): an instance of the reference's tile rectangle
+// (Options::bucket_cstride, default 4.)
+// Tight tile culling (Options::tile_cull, default on): an instance of the reference's tile rectangle
 // (CR/auxiliary.h:46-56, a square around 3 sigma) whose tile the ellipse {alpha >= 1/255} does not reach is dropped here --
 // every pixel test of that instance would say "skip" (CR/forward.cu:344-349), so images and gradients do not change; lists,
 // n_contrib positions and the per-tile ranges shrink (C3: 1.33 M -> 0.97 M instances).  rank[] keeps a sentinel for them.
-static int g_tile_cull = 1;
-int set_bucket_tile_cull(int on) {
-  if (on != 0 && on != 1) {
-    set_error("tile_cull must be 0 or 1");
-    return GSR_EINVAL;
-  }
-  g_tile_cull = on;
-  return GSR_OK;
-}
 template <bool TIGHT>
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_count_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
                                                                 uint32_t *counts, uint32_t *rank, uint32_t capacity, int CSTRIDE) {
@@ -64,13 +47,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_count_kernel(const GeomState
 // If the instance total exceeds `capacity` (only possible when the host sized the buffer without knowing R) every
 // range is emptied -- nothing is scattered, sorted or blended -- and status[1] is raised for the host to see.
 __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n,
-                                                          const uint32_t *total, uint32_t capacity, uint32_t *status, int CSTRIDE) {
+                                                          const uint32_t *total, uint32_t capacity, uint32_t *status, int CSTRIDE,
+                                                          int check_prefilter) {
   __shared__ uint32_t wtot[1024 / WAVE];
   __shared__ uint32_t carry_s;
   const uint32_t R = *total;
   if (threadIdx.x == 0 && status) {
     status[0] = R;
-    status[1] = R > capacity ? 1u : 0u;
+    status[1] = (R > capacity ? 1u : 0u) | ((check_prefilter && total[1]) ? 2u : 0u);
   }
   if (R > capacity) {
     for (int i = threadIdx.x; i < n; i += 1024) {
@@ -320,7 +304,8 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
 }
 
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *dev_status, hipStream_t stream, int debug) {
+                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, const Options &opt,
+                   hipStream_t stream, int debug) {
   const size_t tiles = (size_t)grid_x * grid_y;
   if (grid_x >= 1024 || grid_y >= 1024) {
     set_error("image larger than 16368 px per side is not supported by the packed tile rect");
@@ -331,10 +316,10 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     return GSR_EINVAL;
   }
   const uint32_t cap32 = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
-  const int CSTRIDE = g_cstride;
+  const int CSTRIDE = opt.bucket_cstride;
   GSR_HIP(hipMemsetAsync(b.tile_counts, 0, tiles * CSTRIDE * sizeof(uint32_t), stream));
   // instance ranks live in the (otherwise unused in this back-end) vals_a array
-  if (g_tile_cull)
+  if (opt.tile_cull)
     hipLaunchKernelGGL(bucket_count_kernel<true>, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
                        b.tile_counts, b.vals_a, cap32, CSTRIDE);
   else
@@ -342,7 +327,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
                        b.tile_counts, b.vals_a, cap32, CSTRIDE);
   GSR_LAUNCH_CHECK(stream, debug);
   hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
-                     g.total, cap32, dev_status, CSTRIDE);
+                     g.total, cap32, dev_status, CSTRIDE, check_prefilter ? 1 : 0);
   GSR_LAUNCH_CHECK(stream, debug);
   if (!device_sized && capacity == 0) return GSR_OK;
   hipLaunchKernelGGL(bucket_scatter_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,

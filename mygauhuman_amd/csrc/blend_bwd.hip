@@ -94,9 +94,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // product per hit) and get their own colour-gradient sums sum_pix w * dL_dpix[c]; those are formed from the four kept
 // blending weights right before they are folded, so only 4 extra registers stay live during the group.  Gradient rows
 // have GROWX = 32 columns then: 0..8 as usual, 9 .. 9+CE-1 the extra colour gradients (two atomic instructions).
-template <int SLOTS, int RED, int CE>
+// DET (SLOTS == 1, RED == 0, CE == 0): deterministic mode, see BlendBwdArgs::det_rows.
+template <int SLOTS, int RED, int CE, bool DET = false>
 __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs a) {
   static_assert(CE == 0 || SLOTS == 1, "feature channels are only built for one pixel per lane");
+  static_assert(!DET || (SLOTS == 1 && RED == 0 && CE == 0), "deterministic mode is built for the default configuration");
   constexpr int WPT = 4 / SLOTS;
   constexpr int ROWF = CE > 0 ? GROWX : GROW;
   // SEP: separable reduction (one pixel per lane, lane = 8 ly + lx): per lane only sum r, sum r dy, sum r dy^2 and the three
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
   __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
   __shared__ uint32_t s_id[WAVE + 4];
+  __shared__ uint32_t s_slot[DET ? WAVE + 4 : 1];
 
   const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);
   const uint32_t tile = item / WPT, part = item % WPT;
@@ -215,6 +218,12 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
       s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)));
       s_id[slot] = id;
+      if constexpr (DET) {  // this instance's slot: same rectangle arithmetic as the preprocess (CR/auxiliary.h:46-56)
+        int bx0, by0, bx1, by1;
+        tile_rect(r0.x, r0.y, a.radii[id], a.grid_x, a.grid_y, bx0, by0, bx1, by1);
+        const uint32_t k = (uint32_t)((ty - by0) * (bx1 - bx0) + (tx - bx0));
+        s_slot[slot] = (a.point_offsets[id] - a.tiles_touched[id] + k) * 4u + part;
+      }
       if (CE > 0) {
         const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
 #pragma unroll
@@ -354,7 +363,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
           v = jj == 3 ? ka : v;
           if constexpr (CE == 0) {
             v = jj == 7 ? kb : v;
-            if (row_live && colA < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + colA], v);
+            if constexpr (DET) {
+              if (row_live && colA < NACC) a.det_rows[(size_t)s_slot[g + u_of_row] * GROW + colA] = v;
+            } else {
+              if (row_live && colA < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + colA], v);
+            }
           } else {
             // extra colour sums, a triple at a time: P = (channel 3t | channel 3t+1) packed in the half rows, S = channel 3t+2
             constexpr int NT = CE / 3;
@@ -423,28 +436,253 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   }
 }
 
-static int g_blend_bwd_nw = 4;
-static int g_blend_bwd_red = 0;
-int set_blend_backward_reduce(int mode) {
-  if (mode != 0 && mode != 1) {
-    set_error("blend_bwd_reduce must be 0 (DPP) or 1 (MFMA)");
-    return GSR_EINVAL;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RED = 2: the per-Gaussian sums over the 64 pixels of a quadrant as a matrix product on the (otherwise idle) matrix pipe.
+//
+// For one survivor the nine gradient sums are  sum_p r[p] m_j(p)  (j = 0..5: moments 1, lx, ly, lx^2, lx ly, ly^2 of the
+// QUADRANT-LOCAL pixel coordinate, p = 8 ly + lx) and  sum_p w[p] dL_dpix_c(p)  (c = 0..2): per pixel only TWO values (r, w)
+// depend on the Gaussian, every weight is a per-pixel constant of the wave.  That is  D[16 x 16] = A[16 x 64] B[64 x 16]  with
+//   A rows 0..7  = r of 8 survivors, rows 8..15 = w of the same 8 survivors (pixels along the contraction index),
+//   B cols 0..5  = the moment weights, cols 6..8 = dL_dpix of the wave's pixels, cols 9..15 = 0,
+// sixteen v_mfma_f32_16x16x4_f32 per 8 survivors (exact fp32 FMA chains), in the shadow of other waves' VALU work.  MFMA
+// contracts over lane>>4 and registers, never over the 64 lanes, so (r, w) take one trip through LDS: the pixel lanes write
+// two dwords per survivor, lane (i = l & 15, k = l >> 4) reads back row i, pixels 16k .. 16k+15 (4 ds_read_b128; row stride
+// TRS / pixel-group offset TKO make them bank-conflict free).  The result comes out as (row = lane>>4 *4 + reg, col = lane&15):
+// a DPP row of 16 lanes holds one survivor's 16 columns -- the layout the packed 64-byte gradient row wants.  The raw
+// moments about the quadrant origin are turned into moments about the Gaussian centre (dx = Dx - lx, Dx = mean.x - x0):
+//   sum r (A - la)(B - lb) = A B S0 - B S_la - A S_lb + S_lalb   with per-column choices of A, B in {Dx, Dy, 1}
+// by one more LDS hop of the 16 x 16 tile (each lane fetches the 4 raw sums its column needs).
+// VALU cost of the whole reduction: ~10 instructions per survivor instead of ~42 FMA-equivalents of permlane swaps + DPP.
+constexpr int TRS = 88;  // floats per transposition row (64 pixels in 4 groups of 16 at offsets 0, 20, 40, 60)
+constexpr int TKO = 20;
+constexpr int MG = 8;    // survivors per MFMA group
+
+__global__ __launch_bounds__(WAVE) void blend_backward_mfma_kernel(const BlendBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_t[16 * TRS];
+  __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
+  __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
+  __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
+  __shared__ uint32_t s_id[WAVE + 4];
+
+  const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);
+  const uint32_t tile = item >> 2, part = item & 3;
+  const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+  const uint32_t lane = threadIdx.x;
+  const uint2 range = a.ranges[tile];
+  const int n = (int)(range.y - range.x);
+  const size_t plane = (size_t)a.H * a.W;
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+
+  const int x0 = tx * TILE + (int)(part & 1) * 8, y0 = ty * TILE + (int)(part >> 1) * 8;
+  const float rx0 = (float)x0, rx1 = (float)(x0 + 7), ry0 = (float)y0, ry1 = (float)(y0 + 7);
+  const int px = x0 + (int)(lane & 7), py = y0 + (int)(lane >> 3);
+  const bool inside = px < a.W && py < a.H;
+  const int p = py * a.W + px;
+  const float pxf = (float)px, pyf = (float)py;
+  float T = inside ? a.final_T[p] : 0.f;
+  const int lastc = inside ? (int)a.n_contrib[p] : 0;
+  const float dpix0 = inside ? a.dL_dpix[p] : 0.f;
+  const float dpix1 = inside ? a.dL_dpix[plane + p] : 0.f;
+  const float dpix2 = inside ? a.dL_dpix[2 * plane + p] : 0.f;
+  const float ddep = inside ? a.dL_ddepth[p] : 0.f;
+  const float dalp = inside ? a.dL_dalpha[p] : 0.f;
+  const float Tb = T * (bg0 * dpix0 + bg1 * dpix1 + bg2 * dpix2);  // T_final * (bg . dL_dpix)
+  float X = 0.f;
+  int maxlast = lastc;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxlast = max(maxlast, __shfl_xor(maxlast, d, WAVE));
+  if (maxlast == 0) return;  // (wave-uniform) nothing was blended into this quadrant
+  const int skip = n - maxlast;  // list entries at front positions >= maxlast contribute to none of this wave's pixels
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+  // ---- B operand (16 registers): column j = lane & 15 of the weights of pixels 16 k + t, k = lane >> 4
+  const int mi = (int)(lane & 15), mk = (int)(lane >> 4);
+  s_t[lane] = dpix0;
+  s_t[64 + lane] = dpix1;
+  s_t[128 + lane] = dpix2;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float bw[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const int q = 16 * mk + t;                        // pixel (= lane index of its owner) inside the quadrant
+    const float lx = (float)(q & 7), ly = (float)(q >> 3);
+    float w = 0.f;
+    w = mi == 0 ? 1.f : w;
+    w = mi == 1 ? lx : w;
+    w = mi == 2 ? ly : w;
+    w = mi == 3 ? lx * lx : w;
+    w = mi == 4 ? lx * ly : w;
+    w = mi == 5 ? ly * ly : w;
+    if (mi >= 6 && mi < 9) w = s_t[(mi - 6) * 64 + q];
+    bw[t] = w;
   }
-  g_blend_bwd_red = mode;
-  return GSR_OK;
+  __builtin_amdgcn_wave_barrier();
+  // position of this lane's pixel inside a transposition row, and the row segment this lane reads back
+  const int wpos = TKO * (int)(lane >> 4) + (int)(lane & 15);
+  const float4 *arow = reinterpret_cast<const float4 *>(&s_t[mi * TRS + TKO * mk]);
+  // conversion to moments about the Gaussian centre: which raw sums column `mi` needs, and its A / B factors
+  const bool mom_lane = mk < 2 && mi < 6, col_lane = mk >= 2 && mi >= 6 && mi < 9;
+  const int ipP = mi == 1 || mi == 4 ? 2 : (mi == 5 ? 15 : 1);            // S_la: lx for columns 0, 2, 3; ly for 1, 4
+  const int ipQ = mi == 2 ? 1 : (mi == 3 || mi == 4 ? 2 : 15);             // S_lb
+  const int ipR = mi >= 2 && mi <= 4 ? mi + 1 : 15;                        // S_lalb (column 15 of D is exactly zero)
+  const float aX = (mi == 0 || mi == 2 || mi == 3) ? 1.f : 0.f, aY = (mi == 1 || mi == 4) ? 1.f : 0.f, a1 = mi == 5 ? 1.f : 0.f;
+  const float bX = mi == 2 ? 1.f : 0.f, bY = (mi == 3 || mi == 4) ? 1.f : 0.f, b1 = (mi < 2 || mi == 5) ? 1.f : 0.f;
+  const float fx0 = (float)x0, fy0 = (float)y0;
+
+  for (int base = skip; base < n; base += WAVE) {
+    // ---- fetch 64 entries (from the back), cull, compact into LDS in back-to-front order
+    const int idx = base + (int)lane;
+    bool keep = false;
+    float4 r0 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
+    const float4 *src = nullptr;
+    uint32_t id = 0;
+    if (idx < n) {
+      id = a.point_list[range.y - 1 - idx];
+      src = reinterpret_cast<const float4 *>(a.recs + id);
+      r0 = src[0];
+      r2 = src[2];
+      keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
+    }
+    float4 r1 = make_float4(0, 0, 0, 0);
+    if (keep) {  // second, exact filter: ellipse {alpha >= 1/255} against the wave's pixel rectangle
+      r1 = src[1];
+      keep = ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rx0, rx1, ry0, ry1);
+    }
+    const uint64_t kmask = __ballot(keep);
+    const int cnt = __builtin_popcountll(kmask);
+    if (keep) {
+      const int slot = __builtin_popcountll(kmask & lt);
+      constexpr float L2E = 1.4426950408889634f;
+      s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
+      s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
+      s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)));
+      s_id[slot] = id;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int g = 0; g < cnt; g += MG) {
+      const int ng = min(MG, cnt - g);
+      uint32_t anyhit = 0;
+      for (int u = 0; u < ng; u++) {  // a real loop: nothing of a survivor stays in registers
+        const float4 g0 = s0[g + u];
+        const float4 g1 = s1[g + u];
+        const float4 g2 = s2[g + u];
+        const int fpos = (int)__float_as_uint(g2.w);  // 0-based position from the front
+        const float dx = g0.x - pxf, dy = g0.y - pyf;
+        const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
+        const bool pre = (fpos < lastc) && !(p2 > 0.0f) && (p2 + g2.z >= -0.02f);
+        if (__ballot(pre) != 0ull) {
+          const float G = __builtin_amdgcn_exp2f(p2);
+          const float alpha = fminf(0.99f, g1.y * G);
+          const bool hit = pre && !(alpha < 1.0f / 255.0f);
+          if (__ballot(hit) != 0ull) {
+            float r = 0.f, w = 0.f;
+            if (hit) {  // exec-masked body: state changes on hit lanes only
+              const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+              const float Tn = T * rc;  // transmittance in front of this Gaussian
+              w = alpha * Tn;           // blending weight = d(pixel)/d(colour)
+              const float e = g1.w * dpix0 + g2.x * dpix1 + g2.y * dpix2 + g1.z * ddep + dalp;
+              const float dL_dalpha = Tn * e - (X + Tb) * rc;
+              X += w * e;
+              T = Tn;
+              r = G * dL_dalpha;
+            }
+            s_t[u * TRS + wpos] = r;
+            s_t[(MG + u) * TRS + wpos] = w;
+            anyhit |= 1u << u;
+          }
+        }
+      }
+      if (anyhit) {  // wave-uniform
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 a0 = arow[0], a1v = arow[1], a2 = arow[2], a3 = arow[3];
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};  // two chains: a dependent MFMA waits 40 cycles, an independent one 32
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bw[0], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bw[1], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bw[2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bw[3], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.x, bw[4], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.y, bw[5], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.z, bw[6], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v.w, bw[7], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bw[8], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bw[9], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, bw[10], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, bw[11], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, bw[12], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, bw[13], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, bw[14], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, bw[15], d1, 0, 0, 0);
+        d0 += d1;
+        // rows 0..7 of D (lanes with mk < 2): raw moments of survivors g .. g+7; rows 8..15: their colour sums
+        __builtin_amdgcn_wave_barrier();
+        if (mk < 2) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) s_t[(4 * mk + r) * 16 + mi] = d0[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int R = 4 * (mk & 1) + r;  // survivor of the group this lane's register r belongs to
+          const bool live = (anyhit >> R) & 1u;
+          float v = d0[r];
+          if (mom_lane) {
+            const float *S = &s_t[R * 16];
+            const float2 c = *reinterpret_cast<const float2 *>(&s0[g + R]);
+            const float Dx = c.x - fx0, Dy = c.y - fy0;
+            const float A = aX * Dx + (aY * Dy + a1), B = bX * Dx + (bY * Dy + b1);
+            v = A * (B * S[0] - S[ipQ]) - B * S[ipP] + S[ipR];
+          }
+          if (live && (mom_lane || col_lane)) atomicAdd(&a.grad_rows[(size_t)s_id[g + R] * GROW + mi], v);
+        }
+        __builtin_amdgcn_wave_barrier();  // the next group's (r, w) rows overwrite the tile
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // keep the next batch's LDS writes behind this batch's reads
+  }
 }
-int set_blend_backward_waves(int nw) {
-  if (nw != 1 && nw != 2 && nw != 4) {
-    set_error("blend_bwd_waves must be 1, 2 or 4");
-    return GSR_EINVAL;
-  }
-  g_blend_bwd_nw = nw;
+
+// deterministic mode, second step: one thread per (Gaussian, column) adds the Gaussian's slots in index order
+__global__ void reduce_det_rows_kernel(int P, const uint32_t *point_offsets, const uint32_t *tiles_touched, const float *det_rows,
+                                       size_t n_slots, float *grad_rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = i >> 4, col = i & 15;
+  if (g >= P) return;
+  uint32_t n = tiles_touched[g] * 4u;
+  if ((size_t)point_offsets[g] * 4u > n_slots) n = 0;  // a forward that overflowed its capacity rendered nothing: no slots exist
+  const float *src = det_rows + (size_t)(point_offsets[g] - tiles_touched[g]) * 4u * GROW + col;
+  float s = 0.f;
+  for (uint32_t k = 0; k < n; k++) s += src[(size_t)k * GROW];
+  grad_rows[(size_t)g * GROW + col] = col < NACC ? s : 0.f;
+}
+int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t *tiles_touched, const float *det_rows,
+                           size_t n_slots, float *grad_rows, hipStream_t stream) {
+  if (P == 0) return GSR_OK;
+  hipLaunchKernelGGL(reduce_det_rows_kernel, dim3((P * 16 + 255) / 256), dim3(256), 0, stream, P, point_offsets, tiles_touched,
+                     det_rows, n_slots, grad_rows);
   return GSR_OK;
 }
 
-int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream) {
+int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
+  if (a.det_rows) {
+    if (a.CE != 0) {
+      set_error("deterministic backward: only the plain pass (no extra feature channels) is built");
+      return GSR_EINVAL;
+    }
+    hipLaunchKernelGGL((blend_backward_kernel<1, 0, 0, true>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    return GSR_OK;
+  }
   if (a.CE != 0) {
     if (a.CE != CE_MAX || !a.extra) {
       set_error("fused feature blend backward: exactly %d extra channels with their arrays are required", CE_MAX);
@@ -453,15 +691,19 @@ int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
-  if (g_blend_bwd_red == 1) {
-    switch (g_blend_bwd_nw) {
+  if (opt.blend_bwd_reduce == 2 && opt.blend_bwd_waves == 4) {
+    hipLaunchKernelGGL(blend_backward_mfma_kernel, dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    return GSR_OK;
+  }
+  if (opt.blend_bwd_reduce == 1) {
+    switch (opt.blend_bwd_waves) {
       case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 1, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
       case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 1, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
       default: hipLaunchKernelGGL((blend_backward_kernel<1, 1, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
     }
     return GSR_OK;
   }
-  switch (g_blend_bwd_nw) {
+  switch (opt.blend_bwd_waves) {
     case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 0, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 0, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
     default: hipLaunchKernelGGL((blend_backward_kernel<1, 0, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;

@@ -168,17 +168,7 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   }
 }
 
-static int g_blend_fwd_nw = 4;
-int set_blend_forward_waves(int nw) {
-  if (nw != 1 && nw != 2 && nw != 4) {
-    set_error("blend_fwd_waves must be 1, 2 or 4");
-    return GSR_EINVAL;
-  }
-  g_blend_fwd_nw = nw;
-  return GSR_OK;
-}
-
-int launch_blend_forward(const BlendFwdArgs &a, hipStream_t stream) {
+int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
   if (a.CE != 0) {
@@ -189,7 +179,7 @@ int launch_blend_forward(const BlendFwdArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
-  switch (g_blend_fwd_nw) {
+  switch (opt.blend_fwd_waves) {
     case 1: hipLaunchKernelGGL((blend_forward_kernel<4, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
     case 2: hipLaunchKernelGGL((blend_forward_kernel<2, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
     default: hipLaunchKernelGGL((blend_forward_kernel<1, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;

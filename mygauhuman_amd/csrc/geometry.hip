@@ -127,7 +127,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
     const float3 p = make_float3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
     const float3 pv = xform4x3(p, a.view);
     if (pv.z <= 0.2f) {  // CR/auxiliary.h:154
-      if (a.prefiltered) __builtin_trap();  // CR/auxiliary.h:156-160
+      // The reference prints "Point is filtered although prefiltered is set" and traps the whole context here
+      // (CR/auxiliary.h:156-160).  A trap aborts the queue and the process; instead the point is culled like any other and a
+      // flag word next to R is raised, which the host turns into GSR_EINVAL / a RuntimeError with the reference's message.
+      if (a.prefiltered) atomicOr(&a.geom.total[1], 1u);
     } else {
       const float4 ph = xform4x4(p, a.proj);
       const float pw = 1.0f / (ph.w + 0.0000001f);

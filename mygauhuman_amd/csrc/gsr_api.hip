@@ -5,7 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -44,15 +46,59 @@ static uint32_t higher_msb(uint32_t n) {
   return msb;
 }
 
-static int g_binning_mode = GSR_BINNING_TILE_BUCKET;
+// ---- options: process defaults + per-stream overrides, resolved once per call (gsr_common.h: Options) ----------------
+static std::mutex g_opt_mutex;
+static Options g_default_opt;
+static std::unordered_map<hipStream_t, Options> g_stream_opt;
 
-// pinned host word for the one device->host read of a forward call (num_rendered, CR/rasterizer_impl.cu:283)
-static int readback_u32(const uint32_t *dev, uint32_t *out, hipStream_t stream) {
+Options options_for(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_opt_mutex);
+  auto it = g_stream_opt.find(stream);
+  return it == g_stream_opt.end() ? g_default_opt : it->second;
+}
+
+static int set_option(Options &o, const char *key, int v) {
+  auto bad = [&](const char *what) {
+    set_error("%s must be %s", key, what);
+    return GSR_EINVAL;
+  };
+  if (!strcmp(key, "binning_mode")) {
+    if (v != GSR_BINNING_GLOBAL_RADIX && v != GSR_BINNING_TILE_BUCKET) return bad("0 (global radix) or 1 (tile bucket)");
+    o.binning_mode = v;
+  } else if (!strcmp(key, "blend_fwd_waves")) {
+    if (v != 1 && v != 2 && v != 4) return bad("1, 2 or 4");
+    o.blend_fwd_waves = v;
+  } else if (!strcmp(key, "blend_bwd_waves")) {
+    if (v != 1 && v != 2 && v != 4) return bad("1, 2 or 4");
+    o.blend_bwd_waves = v;
+  } else if (!strcmp(key, "bucket_cstride")) {
+    if (v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return bad("1, 2, 4, 8 or 16");
+    o.bucket_cstride = v;
+  } else if (!strcmp(key, "tile_cull")) {
+    if (v != 0 && v != 1) return bad("0 or 1");
+    o.tile_cull = v;
+  } else if (!strcmp(key, "blend_bwd_reduce")) {
+    if (v < 0 || v > 2) return bad("0 (DPP), 1 (MFMA on folded rows) or 2 (transposed MFMA contraction)");
+    o.blend_bwd_reduce = v;
+  } else if (!strcmp(key, "deterministic")) {
+    if (v != 0 && v != 1) return bad("0 or 1");
+    o.deterministic = v;
+  } else {
+    set_error("unknown tuning key %s", key);
+    return GSR_EINVAL;
+  }
+  return GSR_OK;
+}
+
+// pinned host words for the one device->host read of a forward call: num_rendered (CR/rasterizer_impl.cu:283) and the
+// "filtered although prefiltered" flag word next to it
+static int readback_u32x2(const uint32_t *dev, uint32_t *out, hipStream_t stream) {
   static thread_local uint32_t *pinned = nullptr;
   if (!pinned) GSR_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 64, hipHostMallocDefault));
-  GSR_HIP(hipMemcpyAsync(pinned, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  GSR_HIP(hipMemcpyAsync(pinned, dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   GSR_HIP(hipStreamSynchronize(stream));
-  *out = *pinned;
+  out[0] = pinned[0];
+  out[1] = pinned[1];
   return GSR_OK;
 }
 
@@ -61,6 +107,7 @@ struct ProfRec {
   int stage;
   hipEvent_t e0, e1;
 };
+static std::mutex g_prof_mutex;  // the autograd backward thread and the main thread both record stages
 static unsigned g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;           // recorded pairs awaiting collection
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;  // recycled events
@@ -69,6 +116,7 @@ static long g_prof_n[PROF_NSTAGES];
 
 void prof_begin(int stage, hipStream_t stream) {
   if (!(g_prof_mask & (1u << stage))) return;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   ProfRec r;
   r.stage = stage;
   if (!g_prof_pool.empty()) {
@@ -83,13 +131,14 @@ void prof_begin(int stage, hipStream_t stream) {
 }
 void prof_end(int stage, hipStream_t stream) {
   if (!(g_prof_mask & (1u << stage))) return;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   for (size_t i = g_prof_recs.size(); i-- > 0;)
     if (g_prof_recs[i].stage == stage) {
       (void)hipEventRecord(g_prof_recs[i].e1, stream);
       return;
     }
 }
-static void prof_collect() {
+static void prof_collect() {  // caller holds g_prof_mutex
   for (auto &r : g_prof_recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
@@ -101,12 +150,6 @@ static void prof_collect() {
   g_prof_recs.clear();
 }
 
-int set_blend_forward_waves(int nw);
-int set_bucket_counter_stride(int s);
-int set_bucket_tile_cull(int on);
-int set_blend_backward_reduce(int mode);
-int set_blend_backward_waves(int nw);
-
 }  // namespace gsr
 
 using namespace gsr;
@@ -117,22 +160,38 @@ int gsr_version(void) { return 100; }
 const char *gsr_target_arch(void) { return "gfx950"; }
 const char *gsr_last_error(void) { return g_error.c_str(); }
 
-int gsr_set_binning_mode(int mode) {
-  if (mode != GSR_BINNING_GLOBAL_RADIX && mode != GSR_BINNING_TILE_BUCKET) {
-    set_error("unknown binning mode %d", mode);
-    return GSR_EINVAL;
-  }
-  g_binning_mode = mode;
+int gsr_set_tuning(const char *key, int value) {
+  if (!key) return GSR_EINVAL;
+  std::lock_guard<std::mutex> lock(g_opt_mutex);
+  return set_option(g_default_opt, key, value);
+}
+int gsr_set_stream_tuning(gsr_stream_t stream_, const char *key, int value) {
+  if (!key) return GSR_EINVAL;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  std::lock_guard<std::mutex> lock(g_opt_mutex);
+  auto it = g_stream_opt.find(stream);
+  if (it == g_stream_opt.end()) it = g_stream_opt.emplace(stream, g_default_opt).first;  // starts as a copy of the defaults
+  return set_option(it->second, key, value);
+}
+int gsr_clear_stream_tuning(gsr_stream_t stream_) {
+  std::lock_guard<std::mutex> lock(g_opt_mutex);
+  g_stream_opt.erase(reinterpret_cast<hipStream_t>(stream_));
   return GSR_OK;
 }
-int gsr_get_binning_mode(void) { return g_binning_mode; }
+int gsr_set_binning_mode(int mode) { return gsr_set_tuning("binning_mode", mode); }
+int gsr_get_binning_mode(void) {
+  std::lock_guard<std::mutex> lock(g_opt_mutex);
+  return g_default_opt.binning_mode;
+}
 
 int gsr_profile_enable(unsigned stage_mask) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   prof_collect();
   g_prof_mask = stage_mask & ((1u << PROF_NSTAGES) - 1);
   return GSR_OK;
 }
 int gsr_profile_reset(void) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   prof_collect();
   for (int i = 0; i < PROF_NSTAGES; i++) {
     g_prof_ms[i] = 0.0;
@@ -145,21 +204,11 @@ int gsr_profile_read(int stage, double *total_ms, long *launches) {
     set_error("gsr_profile_read: bad arguments");
     return GSR_EINVAL;
   }
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   prof_collect();
   *total_ms = g_prof_ms[stage];
   *launches = g_prof_n[stage];
   return GSR_OK;
-}
-
-int gsr_set_tuning(const char *key, int value) {
-  if (!key) return GSR_EINVAL;
-  if (!strcmp(key, "blend_fwd_waves")) return set_blend_forward_waves(value);
-  if (!strcmp(key, "blend_bwd_waves")) return set_blend_backward_waves(value);
-  if (!strcmp(key, "bucket_cstride")) return set_bucket_counter_stride(value);
-  if (!strcmp(key, "tile_cull")) return set_bucket_tile_cull(value);
-  if (!strcmp(key, "blend_bwd_reduce")) return set_blend_backward_reduce(value);
-  set_error("unknown tuning key %s", key);
-  return GSR_EINVAL;
 }
 
 int gsr_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
@@ -250,6 +299,8 @@ int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStrea
   pa.geom = geom;
   pa.prefiltered = in.prefiltered;
   pa.sh_half = in.sh_half;
+  // flag word of the prefiltered contract (see preprocess_forward_kernel); untouched and unread unless prefiltered is set
+  if (in.prefiltered) GSR_HIP(hipMemsetAsync(geom.total + 1, 0, sizeof(uint32_t), stream));
   prof_begin(PROF_PREPROCESS_FWD, stream);
   int rc = launch_preprocess_forward(pa, stream);
   prof_end(PROF_PREPROCESS_FWD, stream);
@@ -267,12 +318,14 @@ int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStrea
 // host" (asynchronous mode: tile-bucket back-end, kernels read R from geom.total and honour `capacity`).
 int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, const ImageState &img, const int *radii,
                     long R_host, size_t capacity, uint32_t *dev_status, hipStream_t stream) {
+  const Options opt = options_for(stream);
   const int grid_x = (in.width + TILE - 1) / TILE, grid_y = (in.height + TILE - 1) / TILE;
   const size_t tiles = (size_t)grid_x * grid_y;
   int rc;
   prof_begin(PROF_BINNING, stream);
-  if (R_host < 0 || g_binning_mode == GSR_BINNING_TILE_BUCKET) {
-    rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, dev_status, stream, in.debug);
+  if (R_host < 0 || opt.binning_mode == GSR_BINNING_TILE_BUCKET) {
+    rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, dev_status, in.prefiltered != 0,
+                        opt, stream, in.debug);
     if (rc != GSR_OK) return rc;
   } else {
     const size_t R = (size_t)R_host;
@@ -313,7 +366,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   fa.CE = in.n_extra;
   fa.out_extra = in.out_extra;
   prof_begin(PROF_BLEND_FWD, stream);
-  rc = launch_blend_forward(fa, stream);
+  rc = launch_blend_forward(fa, opt, stream);
   prof_end(PROF_BLEND_FWD, stream);
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, in.debug);
@@ -363,9 +416,14 @@ int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, g
 
   rc = forward_stage_a(in, geom, radii, stream);
   if (rc != GSR_OK) return rc;
-  uint32_t R = 0;  // the one device -> host read of the call (CR/rasterizer_impl.cu:283)
-  rc = readback_u32(geom.total, &R, stream);
+  uint32_t rb[2] = {0, 0};  // the one device -> host read of the call (CR/rasterizer_impl.cu:283)
+  rc = readback_u32x2(geom.total, rb, stream);
   if (rc != GSR_OK) return rc;
+  const uint32_t R = rb[0];
+  if (prefiltered && rb[1]) {
+    set_error("Point is filtered although prefiltered is set. This shouldn't happen!");  // CR/auxiliary.h:158
+    return GSR_EINVAL;
+  }
   *host_num_rendered = (int)R;
   char *bchunk = binning_alloc(binning_user, binning_bytes((size_t)R, tiles));
   if (!bchunk) {
@@ -481,7 +539,15 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
     return GSR_EINVAL;
   }
   const int grow = n_extra ? GROWX : GROW;
-  GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * grow * sizeof(float), stream));
+  const Options opt = options_for(stream);
+  float *det_rows = nullptr;
+  const size_t det_bytes = (size_t)(R > 0 ? R : 1) * 4 * GROW * sizeof(float);
+  if (opt.deterministic) {  // one 64-byte slot per (instance, quadrant), zeroed: culled instances keep zeros
+    GSR_HIP(hipMallocAsync(reinterpret_cast<void **>(&det_rows), det_bytes, stream));
+    GSR_HIP(hipMemsetAsync(det_rows, 0, det_bytes, stream));
+  } else {
+    GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * grow * sizeof(float), stream));
+  }
   BlendBwdArgs ba;
   memset(&ba, 0, sizeof(ba));
   ba.ranges = img.ranges;
@@ -505,9 +571,15 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
     ba.dL_dextra_tri[t] = (n_extra && dL_dout_extra) ? dL_dout_extra[t] : nullptr;
     if (ba.dL_dextra_tri[t]) ba.extra_mask |= 1u << t;
   }
+  ba.det_rows = det_rows;
+  ba.radii = radii;
+  ba.point_offsets = geom.point_offsets;
+  ba.tiles_touched = geom.tiles_touched;
   prof_begin(PROF_BLEND_BWD, stream);
-  int rc = launch_blend_backward(ba, stream);
+  int rc = launch_blend_backward(ba, opt, stream);
+  if (rc == GSR_OK && det_rows) rc = launch_reduce_det_rows(P, geom.point_offsets, geom.tiles_touched, det_rows, (size_t)(R > 0 ? R : 1) * 4, geom.grad_rows, stream);
   prof_end(PROF_BLEND_BWD, stream);
+  if (det_rows) (void)hipFreeAsync(det_rows, stream);
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, debug);
 

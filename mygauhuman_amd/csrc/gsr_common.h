@@ -39,7 +39,7 @@ struct GeomState {  // per Gaussian
   uint32_t *block_incl;     // [P] block-local inclusive scan of tiles_touched
   uint32_t *block_sums;     // [nblk]
   uint32_t *block_prefix;   // [nblk] exclusive prefix of block_sums
-  uint32_t *total;          // [1] R
+  uint32_t *total;          // [4] R; [1] = "a point was filtered although prefiltered is set" (valid only in prefiltered calls)
   float *grad_rows;         // [P][GROW or GROWX] backward accumulation rows (zeroed by the backward)
 };
 struct BinningState {  // per instance
@@ -145,6 +145,22 @@ enum ProfStage { PROF_PREPROCESS_FWD = 0, PROF_SCAN = 1, PROF_BINNING = 2, PROF_
 void prof_begin(int stage, hipStream_t stream);
 void prof_end(int stage, hipStream_t stream);
 
+// ---- per-call options (gsr_api.hip) ----------------------------------------------------------------------------------
+// Every knob a call consults.  A call resolves them ONCE, at entry, from its stream: options set for that stream with
+// gsr_set_stream_tuning, else the process defaults (gsr_set_tuning / gsr_set_binning_mode).  Nothing below the API layer
+// reads mutable global state, so calls on different streams -- from any threads, the autograd backward thread included --
+// do not see each other's knobs.
+struct Options {
+  int binning_mode = GSR_BINNING_TILE_BUCKET;
+  int tile_cull = 1;         // exact ellipse-vs-tile culling of instances in the tile-bucket back-end
+  int bucket_cstride = 4;    // counters per 64-byte line = 16 / stride (interleaved A/B at C3, us of binning: 1: 112, 2: 106, 4: 100, 16: 126)
+  int blend_fwd_waves = 4;   // waves that cooperate on one 16x16 tile
+  int blend_bwd_waves = 4;
+  int blend_bwd_reduce = 0;  // 0 DPP / permlane, 1 MFMA on folded rows, 2 transposed MFMA contraction
+  int deterministic = 0;     // backward: fixed-order reduction of the gradient rows instead of float atomics
+};
+Options options_for(hipStream_t stream);
+
 // ---- kernel launchers (one translation unit each) ---------------------------------------------
 struct PreprocessArgs {
   int P, D, M;
@@ -184,7 +200,7 @@ struct BlendFwdArgs {
   int CE;              // 0 or CE_MAX
   float *out_extra;    // [CE][H][W]
 };
-int launch_blend_forward(const BlendFwdArgs &a, hipStream_t stream);
+int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream);
 
 struct BlendBwdArgs {
   const uint2 *ranges;
@@ -200,8 +216,16 @@ struct BlendBwdArgs {
   int CE;
   const float *dL_dextra_tri[CE_MAX / 3];  // per colour triple: [3][H][W] gradient image, null = no gradient
   uint32_t extra_mask;         // bit t: colour triple t (channels 3t..3t+2) has an incoming gradient
+  // deterministic mode (Options::deterministic): the nine sums of a (Gaussian, tile, quadrant) go to their own 64-byte slot
+  // det_rows[((point_offsets[g] - tiles_touched[g] + k) * 4 + quadrant)][GROW], k = index of the tile in the Gaussian's
+  // rectangle, instead of being added atomically; launch_reduce_det_rows sums a Gaussian's slots in index order afterwards
+  float *det_rows;             // null = atomics
+  const int *radii;
+  const uint32_t *point_offsets, *tiles_touched;
 };
-int launch_blend_backward(const BlendBwdArgs &a, hipStream_t stream);
+int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t *tiles_touched, const float *det_rows,
+                           size_t n_slots, float *grad_rows, hipStream_t stream);
+int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t stream);
 
 struct PreprocessBwdArgs {
   int P, D, M;
@@ -226,9 +250,10 @@ int launch_query_recs(int what, int P, const GeomState &g, void *dst, hipStream_
 
 // tile-bucket binning (binning_bucket.hip)
 // capacity = instances the binning buffer holds.  device_sized: the host does not know R; the kernels read it from
-// g.total, write dev_status[0] = R, dev_status[1] = (R > capacity) and render nothing on overflow.
+// g.total, write dev_status[0] = R, dev_status[1] = (R > capacity) | 2 * (prefilter violation) and render nothing on overflow.
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *dev_status, hipStream_t stream, int debug);
+                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, const Options &opt,
+                   hipStream_t stream, int debug);
 
 }  // namespace gsr
 

@@ -149,7 +149,10 @@ def training_setup(model, lrs, percent_dense=0.01):
 def add_densification_stats(model, viewspace_point_tensor, update_filter):
     """scene/gaussian_model.py:764-766.  Same values, written without boolean-mask indexing (which costs a nonzero kernel and
     a host synchronisation per statement): rows outside the filter get + 0."""
-    g = viewspace_point_tensor.grad if viewspace_point_tensor.grad is not None else viewspace_point_tensor
+    g = viewspace_point_tensor.grad
+    if g is None:  # the reference fails here as well (NoneType has no [:, :2]): retain_grad() was lost or backward() did not run
+        raise RuntimeError("add_densification_stats: viewspace_point_tensor.grad is None (call backward() first and keep "
+                           "retain_grad() on the screen-space points)")
     f = update_filter.to(model.denom.dtype).unsqueeze(-1)
     model.xyz_gradient_accum += torch.norm(g[:, :2], dim=-1, keepdim=True) * f
     model.denom += f

@@ -97,55 +97,91 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return rendered.value, out_color, out_depth, out_alpha, radii, geom.tensor, binning.tensor, img.tensor
 
 
+PREFILTER_MSG = "Point is filtered although prefiltered is set. This shouldn't happen!"  # CR/auxiliary.h:158
+
+
 class AsyncCapacity:
     """Capacity policy and deferred overflow checks of the sync-free forward (rasterize_gaussians_async).
 
     The blocking read of num_rendered (CR/rasterizer_impl.cu:283) exists to size the binning buffer.  On a 288 GB part the
-    buffer is simply sized generously instead -- max(MIN, 64 instances per Gaussian, 2 x the largest R seen so far), 24 B per
-    instance -- and the device reports R and an overflow flag into `status`.  The flag travels to pinned host memory with an
-    asynchronous copy; it is examined when the frame's backward starts, at the next forward, or by check_all(): an overflow
-    raises RuntimeError there (the overflowing frame rendered only the background) and the capacity is raised for the retry."""
+    buffer is simply sized generously instead -- max(MIN, 64 instances per Gaussian, 2 x the largest R seen so far on that
+    device), 24 B per instance -- and the device reports R and a flag word into `status`.  The words travel to pinned host memory
+    with an asynchronous copy; they are examined when the frame's backward starts, at the next forward on that device, by
+    check(watch) -- which render() calls itself for frames that will have no backward -- or by check_all(): an overflow raises
+    RuntimeError there (the overflowing frame rendered only the background) and the capacity is raised for the retry.
+    All state is kept per device."""
     MIN = 4 << 20
-    largest_R = 0
-    pending = []
-    _pinned = []  # recycled 2-int pinned host tensors (hipHostMalloc per frame would cost more than the read it replaces)
+    _state = {}  # device index -> dict(largest_R, pending, pinned)
 
     @classmethod
-    def capacity(cls, P):
-        return int(max(cls.MIN, 64 * P, 2 * cls.largest_R))
+    def _dev(cls, device):
+        idx = torch.device(device).index
+        idx = torch.cuda.current_device() if idx is None else idx
+        st = cls._state.get(idx)
+        if st is None:
+            st = cls._state[idx] = dict(largest_R=0, pending=[], pinned=[])
+        return st
+
+    @classmethod
+    def capacity(cls, P, device=None):
+        return int(max(cls.MIN, 64 * P, 2 * cls._dev(device if device is not None else "cuda")["largest_R"]))
 
     @classmethod
     def watch(cls, status, capacity):
-        host = cls._pinned.pop() if cls._pinned else torch.empty(2, dtype=torch.int32).pin_memory()
+        st = cls._dev(status.device)
+        host = st["pinned"].pop() if st["pinned"] else torch.empty(2, dtype=torch.int32).pin_memory()
         host.copy_(status, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(status.device))
-        w = [host, ev, int(capacity), False]
-        cls.pending.append(w)
+        w = [host, ev, int(capacity), False, st]
+        st["pending"].append(w)
         return w
 
     @classmethod
     def _examine(cls, w, wait):
-        if w[3]:
+        if w is None or w[3]:
             return
         if wait:
             w[1].synchronize()
         elif not w[1].query():
             return
         w[3] = True
-        if w in cls.pending:
-            cls.pending.remove(w)
-        R, overflow = int(w[0][0]) & 0xFFFFFFFF, int(w[0][1]) != 0
-        cls._pinned.append(w[0])
-        cls.largest_R = max(cls.largest_R, R)
-        if overflow:
+        st = w[4]
+        if w in st["pending"]:
+            st["pending"].remove(w)
+        R, flags = int(w[0][0]) & 0xFFFFFFFF, int(w[0][1])
+        st["pinned"].append(w[0])
+        st["largest_R"] = max(st["largest_R"], R)
+        if flags & 2:
+            raise RuntimeError("rasterize_gaussians_async: " + PREFILTER_MSG)
+        if flags & 1:
             raise RuntimeError(f"rasterize_gaussians_async: {R} (Gaussian, tile) instances exceeded the binning capacity of {w[2]}; "
                                "that frame rendered only the background.  The capacity has been raised: render it again.")
 
+    KEEP_IN_FLIGHT = 2  # frames whose flag words may still be unread when the next forward is issued
+
     @classmethod
-    def poll(cls):
-        for w in list(cls.pending):
-            cls._examine(w, wait=False)
+    def poll(cls, device=None):
+        """Examine what has arrived without blocking, and BLOCK on watches more than KEEP_IN_FLIGHT frames old (their events
+        fired long ago, so this costs nothing): at most the last KEEP_IN_FLIGHT frames of a loop can be unverified --
+        check_all() / `with AsyncCapacity.frames():` closes that window."""
+        pending = list(cls._dev(device if device is not None else "cuda")["pending"])
+        for k, w in enumerate(pending):
+            cls._examine(w, wait=k < len(pending) - cls.KEEP_IN_FLIGHT)
+
+    @classmethod
+    def frames(cls):
+        """Context manager for forward-only loops over the sync-free rasterizer: every frame issued inside is verified when the
+        block ends (raises for a frame that overflowed)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            try:
+                yield cls
+            finally:
+                cls.check_all()
+        return _cm()
 
     @classmethod
     def check(cls, w):
@@ -153,8 +189,9 @@ class AsyncCapacity:
 
     @classmethod
     def check_all(cls):
-        for w in list(cls.pending):
-            cls._examine(w, wait=True)
+        for st in list(cls._state.values()):
+            for w in list(st["pending"]):
+                cls._examine(w, wait=True)
 
 
 def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
@@ -175,8 +212,8 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
                                   projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
                                   debug, extra=extra)
         return (0,) + tuple(out[1:8]) + ((out[8] if extra is not None else None), None)
-    AsyncCapacity.poll()
-    cap = int(capacity) if capacity is not None else AsyncCapacity.capacity(P)
+    AsyncCapacity.poll(dev)
+    cap = int(capacity) if capacity is not None else AsyncCapacity.capacity(P, dev)
     f32, u8 = torch.float32, torch.uint8
     out_color = torch.empty((3, H, W), dtype=f32, device=dev)
     out_depth = torch.empty((1, H, W), dtype=f32, device=dev)

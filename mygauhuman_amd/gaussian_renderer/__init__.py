@@ -21,7 +21,7 @@ import math
 import torch
 
 from .. import lbs as _lbs
-from ..attributes import frame_attributes, frame_attributes_torch
+from ..attributes import frame_attributes
 from ..covariance import bmm3
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
@@ -89,10 +89,9 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
         _occlusion = opacity.repeat(1, 3)
 
     # covariance in the posed frame, view-dependent colour and the six feature colour sets (:120-198): one HIP kernel
-    # (mygauhuman_amd.attributes); pipe.torch_attributes = True runs the reference's chain of torch ops instead
+    # (mygauhuman_amd.attributes)
     sh_python = override_color is None and pipe.convert_SHs_python
-    attributes = frame_attributes_torch if getattr(pipe, "torch_attributes", False) else frame_attributes
-    cov3D_precomp, colors_precomp, features = attributes(
+    cov3D_precomp, colors_precomp, features = frame_attributes(
         means3D, transforms.reshape(-1, 3, 3), world_normal.reshape(-1, 3), pc.get_scaling, scaling_modifier, pc._rotation,
         pc.get_rotation, albedo, roughness, _occlusion, pc.get_features if sh_python else None, pc.active_sh_degree,
         viewpoint_camera.camera_center, viewpoint_camera.world_view_transform)

@@ -1,12 +1,9 @@
 """SMPL linear-blend skinning of the canonical Gaussians -- host side of the LBS row of the hot path.
 
-Mirrors GaussianModel.coarse_deform_c2source and its helpers (scene/gaussian_model.py:768-1013):
-  batch_rodrigues(_torch)            :982-1013, :894-912
-  get_rigid_transformation_torch     :914-944
-  get_transform_params_torch         :947-980
-  coarse_deform_c2source             :768-872   (same arguments / return tuple; `smpl` replaces self.SMPL_NEUTRAL)
-The joint transforms (24 4x4 matrices) and the per-vertex blend-shape offset tables are a few dozen tiny tensor
-ops per frame and stay torch (they carry the autograd graph of the pose-refinement MLP).  Everything per POINT
+Mirrors GaussianModel.coarse_deform_c2source (scene/gaussian_model.py:768-872: same arguments / return tuple; `smpl` replaces
+self.SMPL_NEUTRAL).  Its helpers (:894-1013: rodrigues, rigid transformation chain, transform parameters) run as ONE
+single-wave HIP kernel each way (csrc/pose.hip, smpl_pose_transforms below); the plain-torch formulation of that chain lives
+with the tests (tests/torch_reference.py) as its checker.  The per-vertex blend-shape offsets are HIP GEMVs.  Everything per POINT
 (nearest SMPL vertex, weight softmax, 24-way blends, 3x3 inverse, offsets, posing, world transform) is ONE HIP
 kernel forward (gsr_lbs_forward) and ONE backward (gsr_lbs_backward) behind a torch.autograd.Function, instead of
 ~40 torch kernels + KNN_CUDA + an autograd graph over [P, 24, 16] intermediates.
@@ -19,48 +16,18 @@ from ._lib import check, lib, ptr
 
 
 def batch_rodrigues(rot_vecs):
-    """Axis-angle [N,3] -> rotation matrices [N,3,3]; angle = |v + 1e-8| like the reference."""
-    n = rot_vecs.shape[0]
-    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
-    rot_dir = rot_vecs / angle
-    cos, sin = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
-    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
-    zeros = torch.zeros((n, 1), dtype=rot_vecs.dtype, device=rot_vecs.device)
-    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(n, 3, 3)
-    ident = torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None]
-    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
-
-
-def get_rigid_transformation_torch(rot_mats, joints, parents):
-    """rot_mats [bs,24,3,3], joints [bs,24,3], parents [24] -> relative transforms [bs,24,4,4] (rest pose removed)."""
-    bs, nj = joints.shape[:2]
-    rel = joints.clone()
-    rel[:, 1:] = rel[:, 1:] - joints[:, parents[1:]]
-    tm = torch.cat([rot_mats, rel[..., None]], dim=-1)
-    pad = torch.zeros((bs, nj, 1, 4), dtype=rot_mats.dtype, device=rot_mats.device)
-    pad[..., 3] = 1
-    tm = torch.cat([tm, pad], dim=-2)
-    chain = [tm[:, 0]]
-    for i in range(1, nj):
-        chain.append(torch.matmul(chain[int(parents[i])], tm[:, i]))
-    tr = torch.stack(chain, dim=1)
-    jh = torch.cat([joints, torch.zeros((bs, nj, 1), dtype=joints.dtype, device=joints.device)], dim=-1)
-    relj = torch.sum(tr * jh[:, :, None], dim=3)
-    return torch.cat([tr[..., :3], (tr[..., 3] - relj)[..., None]], dim=-1)
-
-
-def get_transform_params_torch(smpl, params, rot_mats=None, correct_Rs=None):
-    v_template, shapedirs, betas = smpl["v_template"], smpl["shapedirs"], params["shapes"]
-    v_shaped = v_template[None] + torch.sum(shapedirs[None][..., :betas.shape[-1]] * betas[:, None], dim=-1).float()
-    if rot_mats is None:
-        poses = params["poses"].reshape(-1, 3)
-        rot_mats = batch_rodrigues(poses).view(params["poses"].shape[0], -1, 3, 3)
-        if correct_Rs is not None:
-            nr = torch.matmul(rot_mats[:, 1:].reshape(-1, 3, 3), correct_Rs.reshape(-1, 3, 3))
-            rot_mats = torch.cat([rot_mats[:, 0:1], nr.reshape(-1, rot_mats.shape[1] - 1, 3, 3)], dim=1)
-    joints = torch.matmul(smpl["J_regressor"][None], v_shaped)
-    A = get_rigid_transformation_torch(rot_mats, joints, list(parents_host(smpl)))
-    return A, params["R"], params["Th"], joints
+    """Axis-angle vectors [N,3] -> rotation matrices [N,3,3] by Rodrigues' formula in its outer-product form
+    R = cos(t) I + sin(t) [n]x + (1 - cos(t)) n n^T, with t = |v + 1e-8| and n = v / t (the epsilon convention of
+    smplx/lbs.py:batch_rodrigues, which the golden vectors pin).  Host-side helper of smplx_lbs (BASELINE config 1); the
+    per-frame pose path of render() runs csrc/pose.hip instead."""
+    theta = (rot_vecs + 1e-8).norm(dim=1)
+    n = rot_vecs / theta[:, None]
+    c, s_ = torch.cos(theta)[:, None, None], torch.sin(theta)[:, None, None]
+    cross = torch.zeros((rot_vecs.shape[0], 3, 3), dtype=rot_vecs.dtype, device=rot_vecs.device)
+    cross[:, 0, 1], cross[:, 0, 2], cross[:, 1, 2] = -n[:, 2], n[:, 1], -n[:, 0]
+    cross = cross - cross.transpose(1, 2)
+    eye = torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)
+    return c * eye + s_ * cross + (1 - c) * (n[:, :, None] * n[:, None, :])
 
 
 class _RowGemv(torch.autograd.Function):
@@ -90,16 +57,16 @@ class _RowGemv(torch.autograd.Function):
 
 
 def pose_offsets(smpl, rot_mats):
-    """(R[1:] - I).flatten() [1,207] @ posedirs^T -> per-vertex offsets [V,3] (gaussian_model.py:805-811,827-839).
-    GPU tensors: one HBM-streaming HIP GEMV (rocBLAS needs 60 us for this 17 MB product); CPU tensors: torch.matmul."""
+    """(R[1:] - I).flatten() [1,207] @ posedirs^T -> per-vertex offsets [V,3] (gaussian_model.py:805-811,827-839): one
+    HBM-streaming HIP GEMV (rocBLAS needs 60 us for this 17 MB product).  No CPU / torch fallback."""
     posedirs = smpl["posedirs"]
     V = smpl["v_template"].shape[0]
     ident = torch.eye(3, dtype=rot_mats.dtype, device=rot_mats.device)
     feat = (rot_mats[:, 1:] - ident).reshape(rot_mats.shape[0], -1)
     pd = posedirs.reshape(V * 3, -1)
-    if pd.is_cuda and feat.shape[0] == 1 and pd.shape[1] <= 256 and pd.dtype == torch.float32:
-        return _RowGemv.apply(pd, feat[0]).view(V, 3)
-    return torch.matmul(feat, pd.t()).view(-1, V, 3)[0]
+    if not (pd.is_cuda and feat.shape[0] == 1 and pd.shape[1] <= 256 and pd.dtype == torch.float32):
+        raise RuntimeError("pose_offsets: float32 posedirs [V*3, K <= 256] on a HIP device and batch size 1 are required")
+    return _RowGemv.apply(pd, feat[0]).view(V, 3)
 
 
 def shape_offsets(smpl, shapes):
@@ -181,7 +148,6 @@ def smpl_pose_transforms(smpl, params, correct_Rs=None):
     return A[None], rot[None], joints[None]
 
 
-POSE_CHAIN = "hip"              # "hip" (csrc/pose.hip, default) or "torch" (the reference's op chain); same results to fp32 rounding
 NEAREST_VERTEX_SEARCH = "grid"  # "grid" (uniform vertex grid, default) or "brute"; identical results
 
 
@@ -297,19 +263,10 @@ def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_we
     (= self.SMPL_NEUTRAL as device tensors) and the same 6-tuple
     (smpl_src_pts[1,P,3], world_src_pts[1,P,3], bweights[1,P,24], transforms[1,P,3,3], translation|None, world_normals)."""
     assert query_pts.shape[0] == 1, "batch size 1 (like every call site of the reference)"
-    if POSE_CHAIN == "hip":
-        # big pose -> T pose, T pose -> target pose: one single-wave kernel each (csrc/pose.hip)
-        A_big, rot_big, _ = smpl_pose_transforms(smpl, t_params)
-        A_pose, rot_mats, _ = smpl_pose_transforms(smpl, params, correct_Rs)
-        R, Th = params["R"], params["Th"]
-    else:  # the reference's torch chain (kept as the fp32 reference of the pose kernel)
-        A_big, _, _, _ = get_transform_params_torch(smpl, t_params)
-        rot_big = batch_rodrigues(t_params["poses"].view(-1, 3)).view(1, -1, 3, 3)
-        rot_mats = batch_rodrigues(params["poses"].view(-1, 3)).view(1, -1, 3, 3)
-        if correct_Rs is not None:
-            nr = torch.matmul(rot_mats[:, 1:].reshape(-1, 3, 3), correct_Rs.reshape(-1, 3, 3)).reshape(-1, rot_mats.shape[1] - 1, 3, 3)
-            rot_mats = torch.cat([rot_mats[:, 0:1], nr], dim=1)
-        A_pose, R, Th, _ = get_transform_params_torch(smpl, params, rot_mats=rot_mats)
+    # big pose -> T pose, T pose -> target pose: one single-wave kernel each (csrc/pose.hip)
+    A_big, rot_big, _ = smpl_pose_transforms(smpl, t_params)
+    A_pose, rot_mats, _ = smpl_pose_transforms(smpl, params, correct_Rs)
+    R, Th = params["R"], params["Th"]
     off_big = pose_offsets(smpl, rot_big)
     off_shape = shape_offsets(smpl, params["shapes"].to(query_pts.device))
     off_pose = pose_offsets(smpl, rot_mats)

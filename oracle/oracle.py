@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgsr_oracle.so")
+# GSR_ORACLE_LIB selects another build of the same sources (the sanitizer build of the CPU test leg)
+_LIB_PATH = os.environ.get("GSR_ORACLE_LIB") or os.path.join(_HERE, "libgsr_oracle.so")
 _lib = None
 
 f32 = np.float32
@@ -23,6 +24,8 @@ _bp = C.POINTER(C.c_ubyte)
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds)."""
+    if os.environ.get("GSR_ORACLE_LIB"):
+        return _LIB_PATH
     srcs = [os.path.join(_HERE, s) for s in ("gsr_oracle.c", "lbs_oracle.c")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):

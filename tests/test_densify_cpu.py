@@ -4,6 +4,7 @@ applies them in the product is covered by tests/test_gpu_densify.py."""
 import copy
 
 import numpy as np
+import pytest
 import torch
 
 from mygauhuman_amd import densify
@@ -111,10 +112,13 @@ def test_reset_opacity_and_stats_on_cpu_tensors():
     densify.reset_opacity(m)
     assert float(torch.sigmoid(m._opacity.detach()).max()) <= 0.01 + 1e-6
     assert float(m.optimizer.state[m._opacity]["exp_avg"].abs().max()) == 0.0
-    vs = torch.randn(P, 3)
+    vs = torch.zeros(P, 3, requires_grad=True)
     filt = torch.rand(P) > 0.5
+    with pytest.raises(RuntimeError):  # like the reference, a missing screen-space gradient is an error, not a silent + 0
+        densify.add_densification_stats(m, vs, filt)
+    vs.grad = torch.randn(P, 3)
     densify.add_densification_stats(m, vs, filt)
     ref = dict(xyz_gradient_accum=np.zeros((P, 1), np.float32), denom=np.zeros((P, 1), np.float32))
-    do.add_densification_stats(ref, vs.numpy(), filt.numpy())
+    do.add_densification_stats(ref, vs.grad.numpy(), filt.numpy())
     np.testing.assert_allclose(m.xyz_gradient_accum.numpy(), ref["xyz_gradient_accum"], rtol=1e-6)
     np.testing.assert_array_equal(m.denom.numpy(), ref["denom"])

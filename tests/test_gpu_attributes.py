@@ -42,7 +42,8 @@ def _run(fn, d, cam, view, mod, deg, w):
 @pytest.mark.parametrize("P,M,deg,equal", [(1000, 16, 3, False), (777, 16, 2, False), (513, 16, 0, False), (300, 4, 1, False),
                                            (256, 0, 0, False), (400, 16, 3, True), (1, 16, 3, False)])
 def test_frame_attributes_match_torch_chain(P, M, deg, equal):
-    from mygauhuman_amd.attributes import frame_attributes, frame_attributes_torch
+    from mygauhuman_amd.attributes import frame_attributes
+    from tests.torch_reference import frame_attributes_torch
     dev = torch.device("cuda:0")
     d, cam, view = _inputs(P, M, 5 + P, dev, equal)
     g = torch.Generator(device="cpu").manual_seed(P)

@@ -74,3 +74,51 @@ def test_single_gaussian_and_offscreen_only():
             assert float(cols.grad.abs().max()) == 0 and float(alpha.max()) == 0
         else:
             assert float(alpha.max()) > 0.5 and float(extra[2].grad.abs().max()) > 0 and float(extra[0].grad.abs().max()) == 0
+
+
+def test_prefiltered_violation_is_an_error_not_a_device_trap():
+    """prefiltered=True promises that no point fails the frustum test (the reference __trap()s the device otherwise,
+    CR/auxiliary.h:156-160).  Here the call fails with the reference's message and the process lives on."""
+    from mygauhuman_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    P, W, H = 500, 64, 48
+    cam, g = util.make_scene(P, W, H, 4, 1, 0.05, behind_frac=0.1)   # 10 % of the points are behind the camera
+    d = util.to_dev
+    kw = dict(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=d(np.zeros(3, np.float32)),
+              scale_modifier=1.0, viewmatrix=d(cam["viewmatrix"]), projmatrix=d(cam["projmatrix"]), sh_degree=1, campos=d(cam["campos"]),
+              debug=False)
+    args = dict(means3D=d(g["means3D"]), means2D=torch.zeros(P, 3, device="cuda"), opacities=d(g["opacities"]), shs=d(g["shs"]),
+                scales=d(g["scales"]), rotations=d(g["rotations"]))
+    ok = GaussianRasterizer(GaussianRasterizationSettings(prefiltered=False, **kw))(**args)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        GaussianRasterizer(GaussianRasterizationSettings(prefiltered=True, **kw))(**args)
+    # a truthful caller: only the visible points, prefiltered=True -> same image as the unfiltered call
+    vis = GaussianRasterizer(GaussianRasterizationSettings(prefiltered=False, **kw)).markVisible(args["means3D"])
+    sub = {k: v[vis].contiguous() for k, v in args.items()}
+    img = GaussianRasterizer(GaussianRasterizationSettings(prefiltered=True, **kw))(**sub)[0]
+    assert torch.allclose(img, ok[0], atol=1e-6)
+    # sync-free entry: the flag word travels with the overflow flag and raises at the deferred check
+    e = torch.empty(0)
+    out = _C.rasterize_gaussians_async(kw["bg"], args["means3D"], e, args["opacities"], args["scales"], args["rotations"], 1.0, e,
+                                       kw["viewmatrix"], kw["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, args["shs"], 1,
+                                       kw["campos"], True, False)
+    with pytest.raises(RuntimeError, match="filtered although prefiltered"):
+        _C.AsyncCapacity.check(out[9])
+
+
+def test_async_capacity_context_manager_verifies_trailing_frames():
+    """Forward-only loop over the sync-free entry: an overflowing LAST frame must not stay silent."""
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    P, W, H = 3000, 96, 64
+    cam, g = util.make_scene(P, W, H, 6, 0, 0.05)
+    d = util.to_dev
+    e = torch.empty(0)
+    a = (d(np.zeros(3, np.float32)), d(g["means3D"]), e, d(g["opacities"]), d(g["scales"]), d(g["rotations"]), 1.0, e,
+         d(cam["viewmatrix"]), d(cam["projmatrix"]), cam["tanfovx"], cam["tanfovy"], H, W, d(g["shs"]), 0, d(cam["campos"]), False, False)
+    with _C.AsyncCapacity.frames():
+        for _ in range(3):
+            _C.rasterize_gaussians_async(*a)
+    with pytest.raises(RuntimeError, match="exceeded the binning capacity"):
+        with _C.AsyncCapacity.frames():
+            _C.rasterize_gaussians_async(*a)
+            _C.rasterize_gaussians_async(*a, capacity=16)  # the last frame of the loop overflows
+    _C.AsyncCapacity.check_all()

@@ -191,7 +191,7 @@ def test_nearest_vertex_grid_equals_brute_and_oracle(oracle, case):
 
 @pytest.mark.parametrize("with_correct", [False, True])
 def test_smpl_pose_kernel_matches_torch_chain(oracle, with_correct):
-    """csrc/pose.hip against the reference's op chain (lbs.batch_rodrigues + get_rigid_transformation_torch) evaluated in
+    """csrc/pose.hip against the torch formulation of the chain (tests/torch_reference.py: rodrigues + rigid_chain) evaluated in
     float64 with autograd: A, rot_mats and the gradients w.r.t. poses, correct_Rs and joints.  Tolerance 1e-4 (fp32)."""
     from mygauhuman_amd import lbs
     rng = np.random.default_rng(21)
@@ -217,7 +217,8 @@ def test_smpl_pose_kernel_matches_torch_chain(oracle, with_correct):
     rot64 = lbs.batch_rodrigues(p64.view(-1, 3)).view(1, 24, 3, 3)
     if c64 is not None:
         rot64 = torch.cat([rot64[:, 0:1], torch.matmul(rot64[0, 1:], c64)[None]], dim=1)
-    A64 = lbs.get_rigid_transformation_torch(rot64, j64[None], list(parents))
+    from tests.torch_reference import rigid_chain
+    A64 = rigid_chain(rot64, j64[None], list(parents))
     ((A64[0] * wA.double()).sum() + (rot64[0] * wR.double()).sum()).backward()
 
     def close(a, b, name):

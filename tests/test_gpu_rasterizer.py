@@ -23,9 +23,9 @@ def _bg(seed):
     return np.random.default_rng(seed + 5).uniform(0, 1, 3).astype(np.float32)
 
 
-@pytest.fixture(scope="module", params=[(1, 0), (2, 0), (4, 0), (4, 1), (2, 1)], ids=lambda p: f"waves{p[0]}red{p[1]}")
+@pytest.fixture(scope="module", params=[(1, 0), (2, 0), (4, 0), (4, 1), (2, 1), (4, 2)], ids=lambda p: f"waves{p[0]}red{p[1]}")
 def waves(request):
-    """(waves per tile, backward reduction: 0 = DPP rows, 1 = MFMA)"""
+    """(waves per tile, backward reduction: 0 = DPP rows, 1 = MFMA on folded rows, 2 = transposed MFMA contraction)"""
     from mygauhuman_amd import _lib
     w, red = request.param
     _lib.set_tuning("blend_fwd_waves", w)
@@ -267,3 +267,84 @@ def test_fp16_sh_storage_equals_fp32_on_rounded_coefficients(P, W, H):
     assert torch.equal(col, a[1]) and torch.equal(rad, a[4])
     with pytest.raises(RuntimeError):   # only the 16-coefficient layout has a half path
         _C.rasterize_gaussians(*args(sh16[:, :9].contiguous()))
+
+
+def test_deterministic_backward_and_per_stream_knobs(oracle):
+    """(1) "deterministic" = fixed-order reduction of the gradient rows: two backward runs give the same BITS, and the values agree
+    with the atomic mode to summation order.  (2) Re-entrancy: two threads drive forward + backward on two streams with
+    different knobs set per stream (binning back-end, culling, wave counts, reduction) at the same time; each must produce
+    exactly what it produces alone (no knob leaks between streams: integer state bit-identical, images bit-identical)."""
+    import threading
+
+    from mygauhuman_amd import _lib
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    P, W, H = 9000, 208, 144
+    cam, g = util.make_scene(P, W, H, 21, 3, 0.03, 0.02)
+    d = util.to_dev
+    bg = d(np.array([0.3, 0.2, 0.1], np.float32))
+    e = torch.empty(0)
+    T = {k: d(g[k]) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+    cm = {k: d(cam[k]) for k in ("viewmatrix", "projmatrix", "campos")}
+    rng = np.random.default_rng(5)
+    dc, dd, da = (d(rng.normal(0, 1, s).astype(np.float32)) for s in ((3, H, W), (1, H, W), (1, H, W)))
+
+    def frame():
+        o = _C.rasterize_gaussians(bg, T["means3D"], e, T["opacities"], T["scales"], T["rotations"], 1.0, e, cm["viewmatrix"],
+                                   cm["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, T["shs"], 3, cm["campos"], False, False)
+        gr = _C.rasterize_gaussians_backward(bg, T["means3D"], o[4], e, T["scales"], T["rotations"], 1.0, e, cm["viewmatrix"],
+                                             cm["projmatrix"], cam["tanfovx"], cam["tanfovy"], dc, dd, da, T["shs"], 3, cm["campos"],
+                                             o[5], o[0], o[6], o[7], o[3], False)
+        ranges = _C.query_state("RANGES", P, o[0], W, H, o[5], o[6], o[7])
+        plist = _C.query_state("POINT_LIST", P, o[0], W, H, o[5], o[6], o[7])
+        return o, gr, ranges, plist
+
+    # ---- (1) determinism
+    ref = frame()
+    _lib.set_tuning("deterministic", 1)
+    try:
+        a, b = frame(), frame()
+    finally:
+        _lib.set_tuning("deterministic", 0)
+    for x, y, z in zip(a[1], b[1], ref[1]):
+        assert torch.equal(x, y)                                         # run-to-run bit-identical
+        util.assert_close("det vs atomics", x.cpu().numpy(), z.cpu().numpy(), tol=2e-5, max_bad_frac=1e-4)
+    want = oracle.rasterize_backward(util.oracle_forward(oracle, cam, g, bg.cpu().numpy(), "sh"), dc.cpu().numpy(), dd.cpu().numpy(),
+                                     da.cpu().numpy())
+    util.assert_close("det vs oracle", a[1][3].cpu().numpy(), want["dL_dmeans3D"], max_bad_frac=2e-4)
+
+    # ---- (2) two streams, two threads, different knobs
+    knobs = [dict(binning_mode=0, blend_fwd_waves=1, blend_bwd_waves=2, blend_bwd_reduce=1),
+             dict(binning_mode=1, tile_cull=1, blend_fwd_waves=4, blend_bwd_waves=4, blend_bwd_reduce=0, deterministic=1)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for st, kn in zip(streams, knobs):
+        for k, v in kn.items():
+            _lib.set_tuning(k, v, stream=st)
+    torch.cuda.synchronize()
+
+    def run(i, out, n):
+        with torch.cuda.stream(streams[i]):
+            for _ in range(n):
+                out[i] = frame()
+        streams[i].synchronize()
+
+    alone = [None, None]
+    for i in range(2):
+        run(i, alone, 1)
+    both = [None, None]
+    th = [threading.Thread(target=run, args=(i, both, 4)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    try:
+        for i in range(2):
+            (o1, g1, r1, p1), (o2, g2, r2, p2) = alone[i], both[i]
+            assert o1[0] == o2[0] and torch.equal(r1, r2) and torch.equal(p1, p2), i   # the stream's own binning back-end ran
+            for x, y in zip(o1[1:5], o2[1:5]):
+                assert torch.equal(x, y), i
+        assert int((alone[0][2][:, 1] - alone[0][2][:, 0]).sum()) > int((alone[1][2][:, 1] - alone[1][2][:, 0]).sum())  # radix: no culling
+        for x, y in zip(alone[1][1], both[1][1]):
+            assert torch.equal(x, y)   # stream 1 is deterministic: concurrent work on the other stream changes nothing
+    finally:
+        for st in streams:
+            _lib.clear_stream_tuning(st)

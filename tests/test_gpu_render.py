@@ -147,8 +147,7 @@ def test_render_with_cached_transforms_and_motion_decoders(oracle):
 
 
 def test_render_pipe_knobs_agree(oracle):
-    """pipe.torch_attributes (the reference's torch op chain), pipe.sync_free_raster and override_color: same images (to fp32
-    rounding) and gradients as the default path."""
+    """pipe.sync_free_raster and override_color: same images (to fp32 rounding) and gradients as the default path."""
     from mygauhuman_amd.gaussian_renderer import render
     s = _human_scene(oracle)
     bg = util.to_dev(np.array([0.3, 0.1, 0.2], np.float32))
@@ -164,7 +163,7 @@ def test_render_pipe_knobs_agree(oracle):
         return {k: o[k].detach().clone() for k in keys}, [None if p.grad is None else p.grad.detach().clone() for p in s.model.parameters()]
 
     base, gbase = run()
-    for variant in (dict(torch_attributes=True), dict(sync_free_raster=True)):
+    for variant in (dict(sync_free_raster=True),):
         out, grads = run(**variant)
         for k in keys:
             d = (out[k] - base[k]).abs()
@@ -187,7 +186,7 @@ def test_render_pipe_knobs_agree(oracle):
 def test_pose_refinement_gradient_hip_chain_equals_torch_chain(oracle):
     """A trainable pose-refinement module (correct_Rs with a parameter): the gradient that reaches it through render() ->
     rasterizer -> attributes -> LBS (dA_pose partials, pose-offset GEMV backward) -> pose kernel must equal the one through the
-    reference's torch pose chain (lbs.POSE_CHAIN = "torch")."""
+    torch formulation of the pose chain (tests/torch_reference.py, patched in for lbs.smpl_pose_transforms)."""
     from mygauhuman_amd import lbs
     from mygauhuman_amd.gaussian_renderer import render
     s = _human_scene(oracle, seed=7, motion=True)
@@ -215,8 +214,10 @@ def test_pose_refinement_gradient_hip_chain_equals_torch_chain(oracle):
     bg = util.to_dev(np.zeros(3, np.float32))
     w_img = torch.rand((3, s.cam_np["H"], s.cam_np["W"]), device="cuda")
     grads = {}
+    from tests.torch_reference import smpl_pose_transforms_torch
+    hip_chain = lbs.smpl_pose_transforms
     for chain in ("hip", "torch"):
-        lbs.POSE_CHAIN = chain
+        lbs.smpl_pose_transforms = hip_chain if chain == "hip" else smpl_pose_transforms_torch
         try:
             dec.delta.grad = None
             wdec.w.grad = None
@@ -224,7 +225,7 @@ def test_pose_refinement_gradient_hip_chain_equals_torch_chain(oracle):
             ((out["render"] * w_img).sum() + out["normal"].mean()).backward()
             grads[chain] = (dec.delta.grad.clone(), wdec.w.grad.clone())
         finally:
-            lbs.POSE_CHAIN = "hip"
+            lbs.smpl_pose_transforms = hip_chain
     for a, b in zip(grads["hip"], grads["torch"]):
         scale = float(b.abs().max())
         assert scale > 0 and float((a - b).abs().max()) < 2e-3 * scale, (float((a - b).abs().max()), scale)

@@ -1,8 +1,10 @@
 """Fused SSIM kernels (csrc/ssim.hip) against the reference's grouped-conv2d formulation (utils/loss_utils.py:36-66, restated in
-mygauhuman_amd.loss_utils.ssim_torch and run in fp32 on the same device; the gradient also against float64)."""
+tests/torch_reference.py: ssim_torch and run in fp32 on the same device; the gradient also against float64)."""
 import numpy as np
 import pytest
 import torch
+
+from tests.torch_reference import ssim_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +17,7 @@ def test_ssim_matches_reference_formulation(shape):
     img1 = (img2 + 0.2 * torch.randn(shape, generator=g).cuda()).clamp(0, 1).requires_grad_(True)
     ref1 = img1.detach().clone().requires_grad_(True)
     v = loss_utils.ssim(img1, img2)
-    r = loss_utils.ssim_torch(ref1 if ref1.dim() == 4 else ref1[None], img2 if img2.dim() == 4 else img2[None])
+    r = ssim_torch(ref1 if ref1.dim() == 4 else ref1[None], img2 if img2.dim() == 4 else img2[None])
     assert abs(float(v.detach()) - float(r.detach())) < 2e-6
     (1.0 - v).backward()
     (1.0 - r).backward()
@@ -23,7 +25,7 @@ def test_ssim_matches_reference_formulation(shape):
     assert float((img1.grad - ref1.grad).abs().max()) < 1e-4 * scale
     # float64 check of the gradient
     d1 = img1.detach().double().requires_grad_(True)
-    r64 = loss_utils.ssim_torch(d1 if d1.dim() == 4 else d1[None], (img2 if img2.dim() == 4 else img2[None]).double())
+    r64 = ssim_torch(d1 if d1.dim() == 4 else d1[None], (img2 if img2.dim() == 4 else img2[None]).double())
     (1.0 - r64).backward()
     assert float((img1.grad.double() - d1.grad).abs().max()) < 2e-5 * scale
 
@@ -35,8 +37,10 @@ def test_ssim_per_image_mode_identical_images_and_fallbacks():
     assert per.shape == (2,) and torch.allclose(per, torch.ones(2, device="cuda"), atol=1e-6)
     y = (x + 0.1).clamp(0, 1)
     a = loss_utils.ssim(x, y, size_average=False)
-    b = loss_utils.ssim_torch(x, y, size_average=False)
+    b = ssim_torch(x, y, size_average=False)
     assert torch.allclose(a, b, atol=2e-6)
-    # other window sizes and CPU tensors take the reference formulation
-    assert abs(float(loss_utils.ssim(x, y, window_size=7)) - float(loss_utils.ssim_torch(x, y, window_size=7))) < 1e-7
-    assert abs(float(loss_utils.ssim(x.cpu(), y.cpu())) - float(loss_utils.ssim_torch(x, y))) < 2e-6
+    # no silent fallbacks: other window sizes and CPU tensors are refused
+    with pytest.raises(RuntimeError):
+        loss_utils.ssim(x, y, window_size=7)
+    with pytest.raises(RuntimeError):
+        loss_utils.ssim(x.cpu(), y.cpu())

@@ -38,7 +38,7 @@ def test_error_reporting_without_a_gpu():
     """Argument errors are detected before any HIP call: status code + thread-local message."""
     from mygauhuman_amd import _lib
     rc = _lib.lib.gsr_set_binning_mode(7)
-    assert rc == -1 and b"binning mode" in _lib.lib.gsr_last_error()
+    assert rc == -1 and b"binning_mode" in _lib.lib.gsr_last_error()
     rc = _lib.lib.gsr_mark_visible(-1, None, None, None, None, None)
     assert rc == -1
     with pytest.raises(_lib.GsrError):

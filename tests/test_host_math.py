@@ -58,8 +58,9 @@ def test_smplx_lbs_and_rodrigues_match_reference_golden(golden_dir):
     np.testing.assert_allclose(A[0].numpy(), g["A"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(Tm[0].numpy(), g["T"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(lbs.batch_rodrigues(T(g["rodrigues_in"])).numpy(), g["rodrigues_out"], rtol=1e-5, atol=1e-6)
-    # get_transform_params_torch builds the same A (same chain, gaussian_model.py:914-980)
+    # the torch checker of the pose kernel builds the same A (same chain, gaussian_model.py:914-980)
+    from tests.torch_reference import pose_transforms_torch
     smpl = dict(v_template=T(g["smpl_v_template"]), shapedirs=T(g["smpl_shapedirs"]), J_regressor=T(g["smpl_J_regressor"]),
                 kintree_table=torch.stack([T(g["smpl_parents"]), torch.arange(24)]))
-    A2, _, _, _ = lbs.get_transform_params_torch(smpl, dict(shapes=T(g["betas"]), poses=T(g["pose"]), R=None, Th=None))
+    A2, _, _, _ = pose_transforms_torch(smpl, dict(shapes=T(g["betas"]), poses=T(g["pose"]), R=None, Th=None))
     np.testing.assert_allclose(A2[0].numpy(), g["A"], rtol=1e-4, atol=2e-6)

@@ -7,13 +7,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mygauhuman_amd import loss_utils  # noqa: E402
+from tests.torch_reference import ssim_torch  # noqa: E402
 
 
 def main():
     for shape in ((1, 3, 512, 512), (1, 3, 1024, 1024)):
         gt = torch.rand(shape, device="cuda")
         res = {}
-        for name, fn in (("fused", loss_utils.ssim), ("conv2d formulation", loss_utils.ssim_torch)):
+        for name, fn in (("fused", loss_utils.ssim), ("conv2d formulation", ssim_torch)):
             x = (gt + 0.1 * torch.randn(shape, device="cuda")).requires_grad_(True)
 
             def step():
