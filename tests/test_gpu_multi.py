@@ -165,13 +165,14 @@ def test_sync_free_forward_multi_equals_blocking_and_reports_overflow(monkeypatc
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
         util.assert_close(k, b[k].grad.cpu().numpy(), a[k].grad.cpu().numpy(), tol=2e-5, max_bad_frac=1e-4)
     _C.AsyncCapacity.check_all()
-    assert _C.AsyncCapacity.largest_R > 0 and not _C.AsyncCapacity.pending
+    st = _C.AsyncCapacity._dev('cuda')
+    assert st['largest_R'] > 0 and not st['pending']
     # undersized capacity: the frame renders only the background and the error is raised at backward
-    monkeypatch.setattr(_C.AsyncCapacity, "capacity", classmethod(lambda cls, n: 64))
+    monkeypatch.setattr(_C.AsyncCapacity, "capacity", classmethod(lambda cls, n, device=None: 64))
     c = leaves()
     out = rast.forward_multi(means3D=c["means3D"], means2D=c["means2D"], opacities=c["opacities"], extra_colors=c["extras"],
                              shs=c["shs"], scales=c["scales"], rotations=c["rotations"], sync_free=True)
     with pytest.raises(RuntimeError, match="binning capacity"):
         out[0].sum().backward()
     assert float((out[0].detach() - util.to_dev(bg)[:, None, None]).abs().max()) == 0.0
-    assert not _C.AsyncCapacity.pending
+    assert not _C.AsyncCapacity._dev('cuda')['pending']
