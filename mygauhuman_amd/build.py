@@ -16,8 +16,10 @@ SOURCES = [
     ("radix_sort.hip", ["-ffp-contract=off"]),
     ("binning_bucket.hip", ["-ffp-contract=off"]),
     ("knn.hip", ["-ffp-contract=off"]),
-    ("blend_fwd.hip", []),
-    ("blend_bwd.hip", []),
+    # the blend kernels are bound by VALU issue: packed-f32 formation by the SLP vectoriser costs register-packing moves and
+    # buys nothing (v_pk_fma_f32 issues at half the rate of v_fma_f32 on gfx950, profiles/r2_ubench_valu_rate.txt)
+    ("blend_fwd.hip", ["-fno-slp-vectorize"]),
+    ("blend_bwd.hip", ["-fno-slp-vectorize"]),
     ("preprocess_bwd.hip", []),
     ("lbs.hip", []),
     ("attributes.hip", []),

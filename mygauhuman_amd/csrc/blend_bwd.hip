@@ -240,9 +240,14 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       uint32_t anyhit = 0;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        wk[u] = 0.f;
+        // one pixel per lane: the sums are assigned where the Gaussian is evaluated and zeroed where it is skipped; several
+        // pixels per lane: zeroed up front and accumulated over the slots
+        bool any_pre = false;
+        if constexpr (SLOTS > 1) {
+          wk[u] = 0.f;
 #pragma unroll
-        for (int k = 0; k < NA; k++) acc[u][k] = 0.f;
+          for (int k = 0; k < NA; k++) acc[u][k] = 0.f;
+        }
         if (g + u < cnt) {  // wave-uniform
           const float4 g0 = s0[g + u];
           const float4 g1 = s1[g + u];
@@ -253,58 +258,70 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
             const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
             const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
             const bool pre = (fpos < lastc[s]) && !(p2 > 0.0f) && (p2 + g2.z >= -0.02f);
-            if (__ballot(pre) != 0ull) {
-              const float G = __builtin_amdgcn_exp2f(p2);
-              const float alpha = fminf(0.99f, g1.y * G);
-              const bool hit = pre && !(alpha < 1.0f / 255.0f);
-              if (__ballot(hit) != 0ull) anyhit |= 1u << u;
-              if (hit) {  // exec-masked body: state and sums change on hit lanes only
-                const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = T[s] * rc;  // transmittance in front of this Gaussian
-                const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
-                float e = g1.w * dpix0[s] + g2.x * dpix1[s] + g2.y * dpix2[s] + g1.z * ddep[s] + dalp[s];
-                if (CE > 0) {
+            if (__ballot(pre) != 0ull) {  // wave-uniform: some lane may reach alpha >= 1/255
+              // Select form instead of an exec-masked block: on lanes that are not hit alpha and G are forced to zero, which
+              // makes every update below an exact no-op (rc = 1, Tn = T, w = 0, r = 0) -- same results, no second ballot,
+              // no mask save / restore, no zero-initialisation of the sums.
+              const float G0 = __builtin_amdgcn_exp2f(p2);
+              const float alpha0 = fminf(0.99f, g1.y * G0);
+              const bool hit = pre && !(alpha0 < 1.0f / 255.0f);
+              const float alpha = hit ? alpha0 : 0.f, G = hit ? G0 : 0.f;
+              const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+              const float Tn = T[s] * rc;  // transmittance in front of this Gaussian
+              const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
+              float e = g1.w * dpix0[s] + g2.x * dpix1[s] + g2.y * dpix2[s] + g1.z * ddep[s] + dalp[s];
+              if (CE > 0) {
 #pragma unroll
-                  for (int t = 0; t < CE / 3; t++)
-                    if ((a.extra_mask >> t) & 1u) {  // wave-uniform
+                for (int t = 0; t < CE / 3; t++)
+                  if ((a.extra_mask >> t) & 1u) {  // wave-uniform
 #pragma unroll
-                      for (int c = 3 * t; c < 3 * t + 3; c++) e += s_x[(g + u) * CE + c] * dxp[c];
-                    }
-                  wk[u] = w;
-                }
-                const float dL_dalpha = Tn * e - (X[s] + Tb[s]) * rc;
-                X[s] += w * e;
-                T[s] = Tn;
-                // moments of r = G * dL_dalpha over the pixels; preprocess_bwd.hip turns them into dL_dmean2D / dL_dconic
-                const float r = G * dL_dalpha;
-                if constexpr (SEP && HIER) {
-                  acc[u][0] += r;  // the x- and y-weights are applied after the folds
-                  acc[u][1] += w * dpix0[s];
-                  acc[u][2] += w * dpix1[s];
-                  acc[u][3] += w * dpix2[s];
-                } else if constexpr (SEP) {
-                  // only the y-weights go in per lane; the x-weights are applied to the COLUMN sums after the folds
-                  const float ry = r * dy;
-                  acc[u][0] += r;
-                  acc[u][1] += ry;
-                  acc[u][2] += ry * dy;
-                  acc[u][3] += w * dpix0[s];
-                  acc[u][4] += w * dpix1[s];
-                  acc[u][5] += w * dpix2[s];
-                } else {
-                  const float rx = r * dx, ry = r * dy;
-                  acc[u][0] += rx;
-                  acc[u][1] += ry;
-                  acc[u][2] += rx * dx;
-                  acc[u][3] += rx * dy;
-                  acc[u][4] += ry * dy;
-                  acc[u][5] += r;
-                  acc[u][6] += w * dpix0[s];
-                  acc[u][7] += w * dpix1[s];
-                  acc[u][8] += w * dpix2[s];
-                }
+                    for (int c = 3 * t; c < 3 * t + 3; c++) e += s_x[(g + u) * CE + c] * dxp[c];
+                  }
               }
+              const float dL_dalpha = Tn * e - (X[s] + Tb[s]) * rc;
+              X[s] += w * e;
+              T[s] = Tn;
+              // moments of r = G * dL_dalpha over the pixels; preprocess_bwd.hip turns them into dL_dmean2D / dL_dconic
+              const float r = G * dL_dalpha;
+              float v[NA];
+              if constexpr (SEP && HIER) {
+                v[0] = r;  // the x- and y-weights are applied after the folds
+                v[1] = w * dpix0[s];
+                v[2] = w * dpix1[s];
+                v[3] = w * dpix2[s];
+              } else if constexpr (SEP) {
+                const float ry = r * dy;  // only the y-weights go in per lane; the x-weights are applied to the COLUMN sums
+                v[0] = r;
+                v[1] = ry;
+                v[2] = ry * dy;
+                v[3] = w * dpix0[s];
+                v[4] = w * dpix1[s];
+                v[5] = w * dpix2[s];
+              } else {
+                const float rx = r * dx, ry = r * dy;
+                v[0] = rx;
+                v[1] = ry;
+                v[2] = rx * dx;
+                v[3] = rx * dy;
+                v[4] = ry * dy;
+                v[5] = r;
+                v[6] = w * dpix0[s];
+                v[7] = w * dpix1[s];
+                v[8] = w * dpix2[s];
+              }
+#pragma unroll
+              for (int k = 0; k < NA; k++) acc[u][k] = SLOTS == 1 ? v[k] : acc[u][k] + v[k];
+              if (CE > 0) wk[u] = w;
+              anyhit |= 1u << u;
+              any_pre = true;
             }
+          }
+        }
+        if constexpr (SLOTS == 1) {
+          if (!any_pre) {  // skipped (wave-uniform): its sums must read as zero in the reduction
+            wk[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NA; k++) acc[u][k] = 0.f;
           }
         }
       }

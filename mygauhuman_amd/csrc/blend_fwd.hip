@@ -44,7 +44,10 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   float pxf[SLOTS], pyf[SLOTS], T[SLOTS], C0[SLOTS], C1[SLOTS], C2[SLOTS], Dp[SLOTS], Wt[SLOTS];
   float X[SLOTS][CE > 0 ? CE : 1];
   uint32_t last[SLOTS];
-  bool inside[SLOTS], done[SLOTS];
+  bool inside[SLOTS];
+  // "done" as a float folded into the alpha-threshold test (0 while the pixel is live, -1e30 once it is saturated or if it
+  // lies outside the image): one v_add instead of a loop-carried lane mask and the scalar juggling that came with it
+  float dbias[SLOTS];
   int pixid[SLOTS];
   // pixel rectangle of this wave (pixel centres), for the cull test
   const int q0 = (int)part * SLOTS, q1 = q0 + SLOTS - 1;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
     pxf[s] = (float)px;
     pyf[s] = (float)py;
     inside[s] = px < a.W && py < a.H;
-    done[s] = !inside[s];
+    dbias[s] = inside[s] ? 0.f : -1e30f;
     pixid[s] = py * a.W + px;
     T[s] = 1.0f;
     C0[s] = C1[s] = C2[s] = Dp[s] = Wt[s] = 0.f;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   for (int base = 0; base < n; base += WAVE) {
     bool all_done = true;
 #pragma unroll
-    for (int s = 0; s < SLOTS; s++) all_done = all_done && done[s];
+    for (int s = 0; s < SLOTS; s++) all_done = all_done && (dbias[s] < 0.f);
     if (__ballot(!all_done) == 0ull) break;
 
     // ---- fetch 64 list entries, cull against the wave's rectangle, compact the survivors into LDS
@@ -121,14 +124,14 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
         const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
         const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
         // cheap necessary condition for alpha >= 1/255:  log2(255*o) + power*log2(e) >= 0  (0.02 safety margin)
-        const bool pre = !done[s] && !(p2 > 0.0f) && (p2 + g2.z >= -0.02f);
+        const bool pre = !(p2 > 0.0f) && ((p2 + g2.z) + dbias[s] >= -0.02f);
         if (__ballot(pre) != 0ull) {
           const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(p2));
           const bool hit = pre && !(alpha < 1.0f / 255.0f);
           const float test_T = T[s] * (1.0f - alpha);
           const bool stop = hit && test_T < 0.0001f;
           const bool blend = hit && !stop;
-          done[s] = done[s] || stop;
+          dbias[s] = stop ? -1e30f : dbias[s];
           const float w = blend ? alpha * T[s] : 0.0f;
           C0[s] += g1.w * w;
           C1[s] += g2.x * w;
