@@ -65,7 +65,9 @@ int gsr_get_binning_mode(void);
  *   "blend_fwd_waves" / "blend_bwd_waves" in {1, 2, 4}: waves that cooperate on one 16x16 tile (a lane owns 4 / waves pixels);
  *   "blend_bwd_reduce" in {0, 1, 2}: cross-lane reduction of the backward: DPP / permlane on the VALU (default), MFMA on the
  *       folded rows, or the transposed MFMA contraction (documented experiments: slower on gfx950);
- *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the tile-bucket back-end;
+ *   "bucket_hist" in {0, 1}: tile-bucket counting without global atomics (per-workgroup LDS histograms + a dense prefix table,
+ *       default) or with one returning global atomic per instance (also taken for tile grids beyond 8192 tiles);
+ *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the atomic variant;
  *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above);
  *   "deterministic" in {0, 1}: the backward reduces its per-(Gaussian, tile-quadrant) partial sums in a fixed order instead of
  *       with float atomics: run-to-run bit-identical gradients (for tests; costs a 256-byte slot per instance quadrant).

@@ -97,6 +97,150 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
   });
 }
 
+// ---- atomics-free counting (Options::bucket_hist, default on) ---------------------------------------------------------------
+// The count pass above is bound by the memory side: one scattered 4-byte returning atomic per instance is one 64-byte request
+// each (~25 k requests / us chip-wide: 0.97 M instances = 34 us at C3).  Here no instance touches a global atomic:
+//   hist    : a workgroup owns HG consecutive preprocess blocks, keeps one counter per TILE in LDS, and every instance takes
+//             its rank among the workgroup's instances of that tile with an LDS returning add; per instance it leaves
+//             (tile << 16 | rank) and the Gaussian id in instance order (coalesced), the counters go out as one dense row
+//             table[workgroup][tile]
+//   prefix  : 64 tiles x 16 waves per workgroup: every column becomes an exclusive prefix over the workgroups, tile totals out
+//   (tile scan as before: ranges / start)
+//   scatter : flat over the instances of a workgroup, no expansion: slot = start[tile] + table[workgroup][tile] + rank
+// The arrival order inside a tile is as arbitrary as with atomics; the per-tile sort makes the result deterministic.
+constexpr int HG = 2;                  // preprocess blocks per histogram workgroup
+constexpr int HB = HG * PRE_BLOCK;     // Gaussians (= threads) per histogram workgroup
+constexpr int HIST_MAX_TILES = 8192;   // LDS counters: 32 KB (larger tile grids take the atomic path)
+
+template <bool TIGHT>
+__global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, const int *radii, int P, int gx, int gy, int tiles,
+                                                        uint32_t *table, uint32_t *rank, uint32_t *gids, uint32_t capacity) {
+  __shared__ uint32_t s_cnt[HIST_MAX_TILES];
+  __shared__ uint32_t s_incl[HB];
+  __shared__ uint32_t s_rect[HB];  // x0 | y0 << 10 | width << 20
+  __shared__ float4 s_geo[TIGHT ? HB : 1];   // x, y, conic a, conic b
+  __shared__ float2 s_geo2[TIGHT ? HB : 1];  // conic c, opacity
+  const int first = blockIdx.x * HB;
+  const int i = first + (int)threadIdx.x;
+  const uint32_t sb_prefix = g.block_prefix[blockIdx.x * HG];
+  for (int t = threadIdx.x; t < tiles; t += HB) s_cnt[t] = 0;
+  uint32_t incl = 0xFFFFFFFFu, rect = 0;
+  if (i < P) {
+    // inclusive scan of tiles_touched inside this workgroup = block-local scan + the block's offset inside the group
+    incl = g.block_incl[i] + (g.block_prefix[i / PRE_BLOCK] - sb_prefix);
+    g.point_offsets[i] = sb_prefix + incl;
+    const int rad = radii[i];
+    if (rad > 0) {
+      const float4 r0 = reinterpret_cast<const float4 *>(g.recs + i)[0];
+      int x0, y0, x1, y1;
+      tile_rect(r0.x, r0.y, rad, gx, gy, x0, y0, x1, y1);
+      rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
+      if (TIGHT) {
+        const float4 r1 = reinterpret_cast<const float4 *>(g.recs + i)[1];
+        s_geo[threadIdx.x] = r0;
+        s_geo2[threadIdx.x] = make_float2(r1.x, r1.y);
+      }
+    }
+  }
+  s_incl[threadIdx.x] = incl;
+  s_rect[threadIdx.x] = rect;
+  __syncthreads();
+  const int nvalid = min(HB, P - first);
+  const uint32_t total = s_incl[nvalid - 1];
+  for (uint32_t k = threadIdx.x; k < total; k += HB) {
+    int lo = 0, hi = nvalid - 1;  // first j with incl[j] > k
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_incl[mid] > k)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    const uint32_t start = lo == 0 ? 0u : s_incl[lo - 1];
+    const uint32_t local = k - start;
+    const uint32_t rc = s_rect[lo];
+    const uint32_t w = rc >> 20, x0 = rc & 1023u, y0 = (rc >> 10) & 1023u;
+    const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+    bool keep = true;
+    if (TIGHT) {
+      const float4 ge = s_geo[lo];
+      const float2 g2 = s_geo2[lo];
+      const float px0 = (float)(tx * TILE), py0 = (float)(ty * TILE);
+      keep = ellipse_hits_rect(ge.x, ge.y, ge.z, ge.w, g2.x, g2.y, px0, px0 + (float)(TILE - 1), py0, py0 + (float)(TILE - 1));
+    }
+    const uint32_t tile = ty * (uint32_t)gx + tx;
+    const uint32_t r = keep ? ((tile << 16) | atomicAdd(&s_cnt[tile], 1u)) : CULLED_INSTANCE;  // LDS returning add, rank < HB
+    const uint32_t inst = sb_prefix + k;
+    if (inst < capacity) {
+      rank[inst] = r;
+      gids[inst] = (uint32_t)(first + lo);
+    }
+  }
+  __syncthreads();
+  uint32_t *row = table + (size_t)blockIdx.x * tiles;
+  for (int t = threadIdx.x; t < tiles; t += HB) row[t] = s_cnt[t];
+}
+
+// column t of table[n_sb][tiles] -> exclusive prefix over the workgroups (in place), totals[t] = the tile's instance count.
+// A workgroup takes 64 tiles (lanes) x PW waves; wave w owns the rows [w * chunk, (w + 1) * chunk): sum them (independent
+// loads), exchange the wave sums through LDS, then re-walk the rows (L2 hits) and write the running prefixes.
+constexpr int PW = 16;
+__global__ __launch_bounds__(PW *WAVE) void bucket_hist_prefix_kernel(uint32_t *table, int n_sb, int tiles, uint32_t *totals) {
+  __shared__ uint32_t s_sum[PW][WAVE];
+  const int lane = threadIdx.x % WAVE, w = threadIdx.x / WAVE;
+  const int t = blockIdx.x * WAVE + lane;
+  const int chunk = (n_sb + PW - 1) / PW;
+  const int r0 = min(n_sb, w * chunk), r1 = min(n_sb, r0 + chunk);
+  uint32_t sum = 0;
+  if (t < tiles) {
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      const uint32_t *p = table + (size_t)r * tiles + t;
+      sum += (p[0] + p[tiles]) + (p[2 * (size_t)tiles] + p[3 * (size_t)tiles]);
+    }
+    for (; r < r1; r++) sum += table[(size_t)r * tiles + t];
+  }
+  s_sum[w][lane] = sum;
+  __syncthreads();
+  uint32_t run = 0, all = 0;
+  for (int k = 0; k < PW; k++) {
+    const uint32_t v = s_sum[k][lane];
+    run += k < w ? v : 0u;
+    all += v;
+  }
+  if (t < tiles) {
+    for (int r = r0; r < r1; r++) {
+      uint32_t *p = table + (size_t)r * tiles + t;
+      const uint32_t c = *p;
+      *p = run;
+      run += c;
+    }
+    if (w == 0) totals[t] = all;
+  }
+}
+
+// one workgroup per histogram workgroup, flat over its instances [block_prefix[sb * HG], ...): the slot bases of all tiles are
+// staged in LDS (start + this workgroup's table row), the depth comes from the Gaussian's record
+__global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, int n_pre, int tiles, const uint32_t *start,
+                                                                const uint32_t *table, const uint32_t *rank, const uint32_t *gids,
+                                                                uint64_t *bucket, uint32_t capacity) {
+  __shared__ uint32_t s_base[HIST_MAX_TILES];
+  const uint32_t R = *g.total;
+  if (R > capacity) return;  // overflow: see bucket_scan_kernel
+  const uint32_t *row = table + (size_t)blockIdx.x * tiles;
+  for (int t = threadIdx.x; t < tiles; t += HB) s_base[t] = start[t] + row[t];
+  const int b0 = blockIdx.x * HG, b1 = min(n_pre, b0 + HG);
+  const uint32_t i0 = g.block_prefix[b0], i1 = b1 < n_pre ? g.block_prefix[b1] : R;
+  __syncthreads();
+  for (uint32_t inst = i0 + threadIdx.x; inst < i1; inst += HB) {
+    const uint32_t r = rank[inst];
+    if (r == CULLED_INSTANCE) continue;
+    const uint32_t gid = gids[inst];
+    const uint32_t dbits = __float_as_uint(g.recs[gid].depth);
+    bucket[s_base[r >> 16] + (r & 0xFFFFu)] = ((uint64_t)dbits << 32) | (uint64_t)gid;
+  }
+}
+
 // bitonic sorting network over keys[0..npow2) by the whole workgroup, starting at merge level kstart (kstart = 2: a full sort;
 // kstart = 2048: the 1024-key runs are already sorted, even runs ascending and odd runs descending)
 template <typename Ptr>
@@ -316,23 +460,47 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     return GSR_EINVAL;
   }
   const uint32_t cap32 = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
-  const int CSTRIDE = opt.bucket_cstride;
-  GSR_HIP(hipMemsetAsync(b.tile_counts, 0, tiles * CSTRIDE * sizeof(uint32_t), stream));
   // instance ranks live in the (otherwise unused in this back-end) vals_a array
-  if (opt.tile_cull)
-    hipLaunchKernelGGL(bucket_count_kernel<true>, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
-                       b.tile_counts, b.vals_a, cap32, CSTRIDE);
-  else
-    hipLaunchKernelGGL(bucket_count_kernel<false>, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
-                       b.tile_counts, b.vals_a, cap32, CSTRIDE);
-  GSR_LAUNCH_CHECK(stream, debug);
-  hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
-                     g.total, cap32, dev_status, CSTRIDE, check_prefilter ? 1 : 0);
-  GSR_LAUNCH_CHECK(stream, debug);
-  if (!device_sized && capacity == 0) return GSR_OK;
-  hipLaunchKernelGGL(bucket_scatter_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
-                     b.tile_cursor, b.vals_a, b.keys_a, cap32);
-  GSR_LAUNCH_CHECK(stream, debug);
+  const int n_sb = (pre_blocks(P) + HG - 1) / HG;
+  // the workgroup x tile table borrows keys_s, which nothing touches before the sort kernels write their final keys into it
+  const bool hist = opt.bucket_hist && tiles <= (size_t)HIST_MAX_TILES && (size_t)n_sb * tiles * sizeof(uint32_t) <= capacity * sizeof(uint64_t);
+  if (hist) {
+    uint32_t *table = reinterpret_cast<uint32_t *>(b.keys_s);
+    if (opt.tile_cull)
+      hipLaunchKernelGGL(bucket_hist_kernel<true>, dim3(n_sb), dim3(HB), 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table,
+                         b.vals_a, b.vals_s, cap32);
+    else
+      hipLaunchKernelGGL(bucket_hist_kernel<false>, dim3(n_sb), dim3(HB), 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table,
+                         b.vals_a, b.vals_s, cap32);
+    GSR_LAUNCH_CHECK(stream, debug);
+    hipLaunchKernelGGL(bucket_hist_prefix_kernel, dim3((unsigned)((tiles + WAVE - 1) / WAVE)), dim3(PW * WAVE), 0, stream, table, n_sb,
+                       (int)tiles, b.tile_counts);
+    GSR_LAUNCH_CHECK(stream, debug);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
+                       g.total, cap32, dev_status, 1, check_prefilter ? 1 : 0);
+    GSR_LAUNCH_CHECK(stream, debug);
+    if (!device_sized && capacity == 0) return GSR_OK;
+    hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, pre_blocks(P), (int)tiles, b.tile_cursor, table,
+                       b.vals_a, b.vals_s, b.keys_a, cap32);
+    GSR_LAUNCH_CHECK(stream, debug);
+  } else {
+    const int CSTRIDE = opt.bucket_cstride;
+    GSR_HIP(hipMemsetAsync(b.tile_counts, 0, tiles * CSTRIDE * sizeof(uint32_t), stream));
+    if (opt.tile_cull)
+      hipLaunchKernelGGL(bucket_count_kernel<true>, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
+                         b.tile_counts, b.vals_a, cap32, CSTRIDE);
+    else
+      hipLaunchKernelGGL(bucket_count_kernel<false>, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
+                         b.tile_counts, b.vals_a, cap32, CSTRIDE);
+    GSR_LAUNCH_CHECK(stream, debug);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
+                       g.total, cap32, dev_status, CSTRIDE, check_prefilter ? 1 : 0);
+    GSR_LAUNCH_CHECK(stream, debug);
+    if (!device_sized && capacity == 0) return GSR_OK;
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
+                       b.tile_cursor, b.vals_a, b.keys_a, cap32);
+    GSR_LAUNCH_CHECK(stream, debug);
+  }
   hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, stream, ranges, b.keys_a, b.vals_s, b.keys_s);
   GSR_LAUNCH_CHECK(stream, debug);
   // (a separate 16 KB-LDS instantiation for 1025..2048 keys was measured: slower -- the register sorts of the runs, not the

@@ -74,6 +74,9 @@ static int set_option(Options &o, const char *key, int v) {
   } else if (!strcmp(key, "bucket_cstride")) {
     if (v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return bad("1, 2, 4, 8 or 16");
     o.bucket_cstride = v;
+  } else if (!strcmp(key, "bucket_hist")) {
+    if (v != 0 && v != 1) return bad("0 or 1");
+    o.bucket_hist = v;
   } else if (!strcmp(key, "tile_cull")) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.tile_cull = v;
