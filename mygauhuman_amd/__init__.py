@@ -11,7 +11,18 @@ mirrors the reference's operator surface:
 callers work unmodified.
 """
 import importlib
+import os
 import sys
+
+# ROCm 7.2 work-around, needed for hipGraph replays (mygauhuman_amd.graph): with the HIP runtime's AQL "graph packet capture"
+# a graph recorded over this library and torch allocations replays WRONG results once other GPU work has run between two
+# replays (measured on MI355X: profiles/r2_graph_packet_capture.txt; every replay is right with the feature off, at the same
+# replay time).  The flag is read when the HIP runtime initialises, so it has to be in the environment before the first HIP
+# call of the process; GRAPH_REPLAY_SAFE records whether that was still possible when this package was imported.
+_torch = sys.modules.get("torch")
+_hip_already_up = bool(_torch is not None and _torch.cuda.is_initialized())
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+GRAPH_REPLAY_SAFE = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and not _hip_already_up
 
 __version__ = "0.1.0"
 

@@ -112,6 +112,10 @@ class AsyncCapacity:
     All state is kept per device."""
     MIN = 4 << 20
     _state = {}  # device index -> dict(largest_R, pending, pinned)
+    # status tensors of forwards that were recorded into a HIP graph (torch.cuda.graph): a captured region cannot hold the pinned
+    # copy / event of watch() (they would bake a host pointer and an unqueryable event into the graph), so those forwards are
+    # checked by the caller after replays: AsyncCapacity.check_graph_status()
+    graph_status = []
 
     @classmethod
     def _dev(cls, device):
@@ -188,6 +192,17 @@ class AsyncCapacity:
         cls._examine(w, wait=True)
 
     @classmethod
+    def check_graph_status(cls):
+        """Synchronously examine the status words of every graph-captured forward (after one or more replays)."""
+        for st in cls.graph_status:
+            R, flags = int(st[0].item()) & 0xFFFFFFFF, int(st[1].item())
+            if flags & 2:
+                raise RuntimeError("rasterize_gaussians_async (graph): " + PREFILTER_MSG)
+            if flags & 1:
+                raise RuntimeError(f"rasterize_gaussians_async (graph): {R} instances exceeded the binning capacity baked into the graph; "
+                                   "the last replay rendered only the background -- capture again with a larger capacity")
+
+    @classmethod
     def check_all(cls):
         for st in list(cls._state.values()):
             for w in list(st["pending"]):
@@ -212,7 +227,9 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
                                   projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
                                   debug, extra=extra)
         return (0,) + tuple(out[1:8]) + ((out[8] if extra is not None else None), None)
-    AsyncCapacity.poll(dev)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        AsyncCapacity.poll(dev)
     cap = int(capacity) if capacity is not None else AsyncCapacity.capacity(P, dev)
     f32, u8 = torch.float32, torch.uint8
     out_color = torch.empty((3, H, W), dtype=f32, device=dev)
@@ -243,7 +260,11 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
             status.data_ptr(), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
             None if out_extra is None else out_extra.data_ptr(), sh_dtype, _stream(dev))
         check(rc, "gsr_rasterize_forward_async")
-        watch = AsyncCapacity.watch(status, cap)
+        if capturing:
+            watch = None
+            AsyncCapacity.graph_status.append(status)
+        else:
+            watch = AsyncCapacity.watch(status, cap)
     return cap, out_color, out_depth, out_alpha, radii, geom, binning, img, out_extra, watch
 
 

@@ -121,7 +121,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
     def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha, *grad_feats):
         rs = ctx.raster_settings
         if ctx.watch is not None:
-            _C.AsyncCapacity.poll()  # non-blocking here: waiting now would keep the backward kernels off the queue
+            _C.AsyncCapacity.poll(ctx.saved_tensors[1].device)  # non-blocking here: waiting now would keep the backward kernels off the queue
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha,
          extra) = ctx.saved_tensors
         H, W = alpha.shape[-2], alpha.shape[-1]

@@ -8,7 +8,10 @@ What changes underneath:
   * the reference rasterises SEVEN times per frame with identical geometry and different colours (:203-272); here the
     seven images come out of ONE fused pass (one preprocess + binning, a 21-channel blend, one backward) with the same
     outputs and gradients; `pipe.separate_feature_passes = True` restores the seven separate calls;
-    `pipe.sync_free_raster = True` drops the per-frame host read of num_rendered (diff_gaussian_rasterization._C.AsyncCapacity).
+  * no per-frame host read of num_rendered (CR/rasterizer_impl.cu:283): the fused pass runs through the sync-free entry with a
+    generous binning capacity and a deferred, never-silent overflow check (diff_gaussian_rasterization._C.AsyncCapacity: examined
+    when the frame's backward runs, at later frames, and by AsyncCapacity.check_all() / `with AsyncCapacity.frames():` for
+    forward-only loops); `pipe.sync_free_raster = False` restores the reference's blocking read.
 `pc` is any object exposing the reference GaussianModel accessors (scene_model.HumanGaussianModel or the reference's own
 class); `viewpoint_camera` exposes FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
 camera_center, smpl_param, big_pose_smpl_param, big_pose_world_vertex (scene/cameras.py:17-74) and optionally
@@ -119,7 +122,7 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
         # fused: one preprocess + binning + a 21-channel blend (and one backward) give the same seven images
         rendered_image, radii, depth, alpha, feats = rasterizer.forward_multi(
             means3D=means3D, means2D=means2D, opacities=opacity, extra_colors=features, shs=shs, colors_precomp=colors_precomp,
-            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, sync_free=getattr(pipe, "sync_free_raster", False))
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, sync_free=getattr(pipe, "sync_free_raster", True))
         rendered_normal, rendered_world_normal, rendered_albedo, rendered_occlusion, rendered_roughness, rendered_axis = feats
 
     return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha, "viewspace_points": screenspace_points,

@@ -147,7 +147,8 @@ def test_render_with_cached_transforms_and_motion_decoders(oracle):
 
 
 def test_render_pipe_knobs_agree(oracle):
-    """pipe.sync_free_raster and override_color: same images (to fp32 rounding) and gradients as the default path."""
+    """pipe.sync_free_raster = False (the reference's blocking read of num_rendered) and override_color: same images (to fp32
+    rounding) and gradients as the default (sync-free) path."""
     from mygauhuman_amd.gaussian_renderer import render
     s = _human_scene(oracle)
     bg = util.to_dev(np.array([0.3, 0.1, 0.2], np.float32))
@@ -163,7 +164,7 @@ def test_render_pipe_knobs_agree(oracle):
         return {k: o[k].detach().clone() for k in keys}, [None if p.grad is None else p.grad.detach().clone() for p in s.model.parameters()]
 
     base, gbase = run()
-    for variant in (dict(sync_free_raster=True),):
+    for variant in (dict(sync_free_raster=False),):  # the default is the sync-free entry; the blocking one must agree
         out, grads = run(**variant)
         for k in keys:
             d = (out[k] - base[k]).abs()
@@ -267,3 +268,43 @@ def test_render_training_loop_with_densification(oracle):
     assert counts[-1] != counts[0]
     for p in model.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_render_step_as_one_graph_equals_eager(oracle):
+    """graph.GraphedFrame: render() forward + loss + backward recorded into one hipGraph; a replay gives the eager step's image
+    bits and gradients, and follows in-place updates of its static inputs (a new pose)."""
+    from mygauhuman_amd.gaussian_renderer import render
+    from mygauhuman_amd.graph import GraphedFrame
+    s = _human_scene(oracle, seed=11)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    bg = util.to_dev(np.array([0.2, 0.3, 0.1], np.float32))
+    params = [p for p in s.model.parameters()]
+    keys = ("render", "render_alpha", "normal", "render_axis")
+
+    def step():
+        o = render(1, s.cam, s.model, pipe, bg)
+        sum(o[k].mean() for k in keys).backward()
+        return o
+
+    def eager():
+        for p in params:
+            p.grad = None
+        o = step()
+        return o["render"].detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in params]
+
+    frame = GraphedFrame(step, warmup=3, zero_grads=params)
+    for trial in range(2):
+        if trial == 1:  # a different pose through the same graph: update the static input in place
+            s.cam.smpl_param["poses"].add_(0.05 * torch.randn_like(s.cam.smpl_param["poses"]))
+        img_e, grads_e = eager()
+        out = frame.replay()   # re-attaches the .grad tensors the captured backward writes
+        torch.cuda.synchronize()
+        frame.check()
+        assert torch.equal(out["render"].detach(), img_e), trial
+        for p, ge in zip(params, grads_e):
+            if ge is None:
+                continue
+            scale = float(ge.abs().max()) + 1e-20
+            assert float((p.grad - ge).abs().max()) / scale < 2e-5, trial
+    # gradients of the captured backward live in the graph's pool: read them through the tensors captured at record time
+    assert all(torch.isfinite(v).all() for v in out.values() if isinstance(v, torch.Tensor) and v.is_floating_point())

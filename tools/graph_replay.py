@@ -60,6 +60,7 @@ def main():
         assert not s.overflowed()
         ref_color, ref_alpha = s.color.clone(), s.alpha.clone()
         ref_grad = None if grads is None else grads["opacity"].clone()
+        ref_all = None if grads is None else {k: v.clone() for k, v in grads.items()}
         eager_ms = timed(step, 200)
         print(f"{name}: eager {eager_ms:.4f} ms/step; capturing ...", flush=True)
         g = torch.cuda.CUDAGraph()
@@ -72,7 +73,36 @@ def main():
         torch.cuda.synchronize()
         ok_img = bool(torch.equal(s.color, ref_color) and torch.equal(s.alpha, ref_alpha))
         ok_grad = True if grads is None else bool(torch.allclose(grads["opacity"], ref_grad, rtol=1e-4, atol=1e-7))
-        # a new camera through the SAME graph: rotate the view matrix in place, replay, compare with eager on that camera
+        if grads is not None:  # replays must not accumulate: the gradient rows are zeroed by a memset node inside the graph
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            ok_grad = ok_grad and bool(torch.allclose(grads["opacity"], ref_grad, rtol=1e-4, atol=1e-7))
+            # eager GPU work between replays (an optimizer step in real life) must not disturb the next replay
+            junk = torch.empty(1 << 22, device=dev)
+            junk.fill_(1.0)
+            float(junk.sum())
+            g.replay()
+            torch.cuda.synchronize()
+            rel = {k: float((grads[k] - ref_all[k]).abs().max() / ref_all[k].abs().max()) for k in grads}
+            ok_grad = ok_grad and max(rel.values()) < 1e-4
+            print(f"{name}: after 4 replays max |grad - ref| / max|ref| per tensor = {rel}", flush=True)
+        # new inputs through the SAME graph: move every Gaussian a little in place, eager reference first, then replay
+        if bwd:
+            for trial in range(3):
+                sc.params["means3D"].add_(0.002 * torch.randn_like(sc.params["means3D"]))
+                step()
+                torch.cuda.synchronize()
+                want = {k: v.clone() for k, v in grads.items()}
+                want_img = s.color.clone()
+                junk = torch.empty(1 << 22, device=dev); junk.fill_(float(trial)); float(junk.sum())
+                for v in grads.values():
+                    v.zero_()
+                g.replay()
+                torch.cuda.synchronize()
+                rel = {k: float((grads[k] - want[k]).abs().max() / want[k].abs().max()) for k in grads}
+                print(f"{name}: moved Gaussians, trial {trial}: image equal {bool(torch.equal(s.color, want_img))}, grads rel {rel}", flush=True)
+                ok_grad = ok_grad and max(rel.values()) < 1e-4
         graph_ms = timed(g.replay, 200)
         assert not s.overflowed()
         out[name] = dict(eager_ms=round(eager_ms, 4), graph_ms=round(graph_ms, 4), image_bits_equal=ok_img, grads_close=ok_grad)

@@ -40,7 +40,7 @@ def main(P=200_000, V=6890, W=1024, H=1024):
     cam = cameras.ViewCamera(cam_np, "cuda", sp, bp, d(vt))
     bg = torch.zeros(3, device="cuda")
     for sep, keys in ((False, PHASE1_KEYS if os.environ.get("KEYS") == "phase1" else ALL_KEYS),) if os.environ.get("PROFILE") else (((False, PHASE1_KEYS), (False, ALL_KEYS), (False, PHASE1_KEYS), (False, ALL_KEYS)) if os.environ.get("ORDER") else ((False, ALL_KEYS), (False, PHASE1_KEYS), (True, ALL_KEYS))):
-        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep, sync_free_raster=bool(os.environ.get("SYNC_FREE")))
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep, sync_free_raster=os.environ.get("SYNC_FREE", "1") != "0")
 
         def step():
             for p in model.parameters():
@@ -49,7 +49,7 @@ def main(P=200_000, V=6890, W=1024, H=1024):
             loss = sum(o[k].mean() for k in keys)
             loss.backward()
             return o
-        for _ in range(12):  # first steps after a change of the loss composition load new torch kernels / grow the allocator
+        for _ in range(30):  # first steps after a change of the loss composition load new torch kernels / grow the allocator
             o = step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
