@@ -111,8 +111,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
 constexpr int HG = 2;                  // preprocess blocks per histogram workgroup
 constexpr int HB = HG * PRE_BLOCK;     // Gaussians (= threads) per histogram workgroup
 constexpr int HIST_MAX_TILES = 8192;   // LDS counters: 32 KB (larger tile grids take the atomic path)
+__device__ __forceinline__ int pre_blocks_dev(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
 
-template <bool TIGHT>
+// SCAN: the second level of the tiles_touched scan (scan_block_sums_kernel: block prefixes and R) is done here as well -- every
+// workgroup adds the block sums in front of it (a few hundred words), writes the prefixes of its own blocks, and the last one
+// writes R -- which saves a single-workgroup launch on the asynchronous path (the blocking path needs R on the host earlier).
+template <bool TIGHT, bool SCAN>
 __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, const int *radii, int P, int gx, int gy, int tiles,
                                                         uint32_t *table, uint32_t *rank, uint32_t *gids, uint32_t capacity) {
   __shared__ uint32_t s_cnt[HIST_MAX_TILES];
@@ -120,14 +124,47 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
   __shared__ uint32_t s_rect[HB];  // x0 | y0 << 10 | width << 20
   __shared__ float4 s_geo[TIGHT ? HB : 1];   // x, y, conic a, conic b
   __shared__ float2 s_geo2[TIGHT ? HB : 1];  // conic c, opacity
+  __shared__ uint32_t s_wsum[HB / WAVE];
+  __shared__ uint32_t s_boff[HG + 1];        // [0] = instances in front of this workgroup, [1 + k] = offset of its block k
   const int first = blockIdx.x * HB;
   const int i = first + (int)threadIdx.x;
-  const uint32_t sb_prefix = g.block_prefix[blockIdx.x * HG];
+  const int b0 = blockIdx.x * HG, n_pre = pre_blocks_dev(P);
   for (int t = threadIdx.x; t < tiles; t += HB) s_cnt[t] = 0;
+  if (SCAN) {
+    uint32_t part = 0;
+    for (int b = threadIdx.x; b < b0; b += HB) part += g.block_sums[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, WAVE);
+    if (threadIdx.x % WAVE == 0) s_wsum[threadIdx.x / WAVE] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t run = 0;
+      for (int w = 0; w < HB / WAVE; w++) run += s_wsum[w];
+      s_boff[0] = run;
+      uint32_t off = 0;
+      for (int k = 0; k < HG; k++) {
+        s_boff[1 + k] = off;
+        if (b0 + k < n_pre) {
+          g.block_prefix[b0 + k] = run + off;
+          off += g.block_sums[b0 + k];
+        }
+      }
+      if (blockIdx.x == gridDim.x - 1) g.total[0] = run + off;  // the last workgroup holds the last blocks: this is R
+    }
+    __syncthreads();
+  } else {
+    if (threadIdx.x <= HG) {
+      const uint32_t base = g.block_prefix[b0];
+      if (threadIdx.x == 0) s_boff[0] = base;
+      else s_boff[threadIdx.x] = (b0 + (int)threadIdx.x - 1 < n_pre ? g.block_prefix[b0 + threadIdx.x - 1] : base) - base;
+    }
+    __syncthreads();
+  }
+  const uint32_t sb_prefix = s_boff[0];
   uint32_t incl = 0xFFFFFFFFu, rect = 0;
   if (i < P) {
     // inclusive scan of tiles_touched inside this workgroup = block-local scan + the block's offset inside the group
-    incl = g.block_incl[i] + (g.block_prefix[i / PRE_BLOCK] - sb_prefix);
+    incl = g.block_incl[i] + s_boff[1 + threadIdx.x / PRE_BLOCK];
     g.point_offsets[i] = sb_prefix + incl;
     const int rad = radii[i];
     if (rad > 0) {
@@ -447,8 +484,14 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
   }
 }
 
+bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity) {
+  const size_t n_sb = (size_t)(pre_blocks(P) + HG - 1) / HG;
+  // the workgroup x tile table borrows keys_s, which nothing touches before the sort kernels write their final keys into it
+  return opt.bucket_hist && tiles <= (size_t)HIST_MAX_TILES && n_sb * tiles * sizeof(uint32_t) <= capacity * sizeof(uint64_t);
+}
+
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, const Options &opt,
+                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, bool scan_fused, const Options &opt,
                    hipStream_t stream, int debug) {
   const size_t tiles = (size_t)grid_x * grid_y;
   if (grid_x >= 1024 || grid_y >= 1024) {
@@ -462,16 +505,29 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   const uint32_t cap32 = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
   // instance ranks live in the (otherwise unused in this back-end) vals_a array
   const int n_sb = (pre_blocks(P) + HG - 1) / HG;
-  // the workgroup x tile table borrows keys_s, which nothing touches before the sort kernels write their final keys into it
-  const bool hist = opt.bucket_hist && tiles <= (size_t)HIST_MAX_TILES && (size_t)n_sb * tiles * sizeof(uint32_t) <= capacity * sizeof(uint64_t);
+  const bool hist = bucket_uses_hist(opt, P, tiles, capacity);
+  if (scan_fused && !hist) {
+    set_error("bucket_binning: the fused block scan needs the histogram path");
+    return GSR_EINVAL;
+  }
   if (hist) {
     uint32_t *table = reinterpret_cast<uint32_t *>(b.keys_s);
-    if (opt.tile_cull)
-      hipLaunchKernelGGL(bucket_hist_kernel<true>, dim3(n_sb), dim3(HB), 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table,
-                         b.vals_a, b.vals_s, cap32);
-    else
-      hipLaunchKernelGGL(bucket_hist_kernel<false>, dim3(n_sb), dim3(HB), 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table,
-                         b.vals_a, b.vals_s, cap32);
+    const dim3 hg(n_sb), hb(HB);
+    if (scan_fused) {
+      if (opt.tile_cull)
+        hipLaunchKernelGGL((bucket_hist_kernel<true, true>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
+                           b.vals_s, cap32);
+      else
+        hipLaunchKernelGGL((bucket_hist_kernel<false, true>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
+                           b.vals_s, cap32);
+    } else {
+      if (opt.tile_cull)
+        hipLaunchKernelGGL((bucket_hist_kernel<true, false>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
+                           b.vals_s, cap32);
+      else
+        hipLaunchKernelGGL((bucket_hist_kernel<false, false>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
+                           b.vals_s, cap32);
+    }
     GSR_LAUNCH_CHECK(stream, debug);
     hipLaunchKernelGGL(bucket_hist_prefix_kernel, dim3((unsigned)((tiles + WAVE - 1) / WAVE)), dim3(PW * WAVE), 0, stream, table, n_sb,
                        (int)tiles, b.tile_counts);

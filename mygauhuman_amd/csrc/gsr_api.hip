@@ -272,7 +272,7 @@ int validate_forward(const FwdIn &in, const char *who) {
 }
 
 // preprocess + device-wide scan of tiles_touched
-int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStream_t stream) {
+int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStream_t stream, bool skip_scan = false) {
   const int grid_x = (in.width + TILE - 1) / TILE, grid_y = (in.height + TILE - 1) / TILE;
   PreprocessArgs pa;
   memset(&pa, 0, sizeof(pa));
@@ -309,6 +309,7 @@ int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStrea
   prof_end(PROF_PREPROCESS_FWD, stream);
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, in.debug);
+  if (skip_scan) return GSR_OK;  // the histogram kernel of the binning does the second scan level itself
   prof_begin(PROF_SCAN, stream);
   rc = launch_scan_block_sums(geom, in.P, stream);
   prof_end(PROF_SCAN, stream);
@@ -320,7 +321,7 @@ int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStrea
 // binning + blend.  capacity = number of instances the binning buffer can hold; R_host < 0 means "unknown on the
 // host" (asynchronous mode: tile-bucket back-end, kernels read R from geom.total and honour `capacity`).
 int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, const ImageState &img, const int *radii,
-                    long R_host, size_t capacity, uint32_t *dev_status, hipStream_t stream) {
+                    long R_host, size_t capacity, uint32_t *dev_status, hipStream_t stream, bool scan_fused = false) {
   const Options opt = options_for(stream);
   const int grid_x = (in.width + TILE - 1) / TILE, grid_y = (in.height + TILE - 1) / TILE;
   const size_t tiles = (size_t)grid_x * grid_y;
@@ -328,7 +329,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   prof_begin(PROF_BINNING, stream);
   if (R_host < 0 || opt.binning_mode == GSR_BINNING_TILE_BUCKET) {
     rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, dev_status, in.prefiltered != 0,
-                        opt, stream, in.debug);
+                        scan_fused, opt, stream, in.debug);
     if (rc != GSR_OK) return rc;
   } else {
     const size_t R = (size_t)R_host;
@@ -485,9 +486,10 @@ int gsr_rasterize_forward_async_ex(char *geom_buffer, char *binning_buffer, size
   if (!radii) radii = geom.internal_radii;
   ImageState img = image_from_chunk(image_buffer, npix, tiles);
   BinningState bin = binning_from_chunk(binning_buffer, binning_capacity, tiles);
-  rc = forward_stage_a(in, geom, radii, stream);
+  const bool scan_fused = bucket_uses_hist(options_for(stream), P, tiles, binning_capacity);
+  rc = forward_stage_a(in, geom, radii, stream, scan_fused);
   if (rc != GSR_OK) return rc;
-  return forward_stage_b(in, geom, bin, img, radii, -1, binning_capacity, dev_status, stream);
+  return forward_stage_b(in, geom, bin, img, radii, -1, binning_capacity, dev_status, stream, scan_fused);
 }
 
 int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t binning_capacity, char *image_buffer, int P,

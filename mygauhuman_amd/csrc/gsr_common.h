@@ -253,8 +253,10 @@ int launch_query_recs(int what, int P, const GeomState &g, void *dst, hipStream_
 // capacity = instances the binning buffer holds.  device_sized: the host does not know R; the kernels read it from
 // g.total, write dev_status[0] = R, dev_status[1] = (R > capacity) | 2 * (prefilter violation) and render nothing on overflow.
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, const Options &opt,
+                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, bool scan_fused, const Options &opt,
                    hipStream_t stream, int debug);
+// true if bucket_binning will take its atomics-free histogram path (which can also do the block-sums scan: scan_fused)
+bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity);
 
 }  // namespace gsr
 

@@ -92,10 +92,16 @@ class RasterSession:
             out["scales"].data_ptr(), out["rotations"].data_ptr(), 0, None, 0, None, None, sh_dtype, self._stream()),
             "gsr_rasterize_backward")
 
+    # `status` may be a device tensor (default) or a pinned host tensor that the kernels write directly (ViewParallelStep)
+    def _status_word(self, k):
+        if not self.status.is_cuda:
+            torch.cuda.synchronize(self.device)
+        return int(self.status[k].item())
+
     def num_rendered(self):
         """R of the last forward (synchronises)."""
-        return int(self.status[0].item())
+        return self._status_word(0) & 0xFFFFFFFF
 
     def overflowed(self):
         """True if the last forward needed more than `capacity` instances and therefore rendered nothing (synchronises)."""
-        return bool(self.status[1].item())
+        return bool(self._status_word(1) & 1)

@@ -233,7 +233,11 @@ class ViewParallelStep:
             ev.synchronize()
             self.pending.popleft()
             self._events.append(ev)
-            ranks, R, own = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2]) != 0
+            if self.world > 1:   # [ranks that overflowed, R, own flag], written by gsr_step_status after the all-reduce
+                ranks, R, own = int(host[0]), int(host[1]) & 0xFFFFFFFF, int(host[2]) != 0
+            else:                # the forward's own status words [R, flags], written straight into this pinned buffer
+                R, own = int(host[0]) & 0xFFFFFFFF, (int(host[1]) & 1) != 0
+                ranks = int(own)
             self._pinned.append(host)
             if ranks > 0:
                 old = self.session.capacity
@@ -252,10 +256,14 @@ class ViewParallelStep:
         """Returns (color, alpha, radii); afterwards self.grads[name] holds the (mean over ranks, if reduce) gradients."""
         self._examine(block_older_than=self.steps - self.max_in_flight)
         s, b = self.session, self.bucket
+        host = self._report_buffer()
+        if self.world == 1:
+            # single process: the forward writes its status words (R, flags) straight into this step's pinned buffer (device-
+            # mapped host memory) -- no bookkeeping kernel, no copy; the event below tells the host when they are there
+            s.status = host
         s.forward(self.p, cam, bg, self.deg)
         dc, da = s.alpha_mask_loss_backward(gt, mask, 0.1)
         s.backward(self.p, cam, bg, self.deg, dc, s.dL_ddepth, da, self.grads)
-        host = self._report_buffer()
         if reduce and self.world > 1:
             self._status(0)
             if self.compact is not None:
@@ -267,8 +275,9 @@ class ViewParallelStep:
             b.flat.mul_(self._scale)
             if self.compact is not None:
                 self.compact.reconstruct(self.p["means3D"], self.deg, self._scale)
-        else:  # (a single process needs no scaling: its own overflowed step has exactly zero gradients already)
+        elif self.world > 1:  # an un-reduced step of a multi-rank job: local bookkeeping only
             self._status(2, host)
+        # (a single process needs no scaling: its own overflowed step has exactly zero gradients already)
         ev = self._events.pop() if self._events else torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self._scale.device))
         self.steps += 1

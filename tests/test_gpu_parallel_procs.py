@@ -120,4 +120,4 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and "REHEARSAL" in d["config"]["workload"]
-    assert d["roofline"]["kernel"] in ("blend_bwd", "blend_fwd")
+    assert d["roofline"]["kernel"] in ("blend_bwd", "blend_fwd", "binning", "preprocess_fwd", "preprocess_bwd")  # two ranks share one GPU here
