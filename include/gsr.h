@@ -63,8 +63,10 @@ int gsr_get_binning_mode(void);
 /* Knobs (images, radii and gradients never change beyond summation order):
  *   "binning_mode" (= gsr_set_binning_mode);
  *   "blend_fwd_waves" / "blend_bwd_waves" in {1, 2, 4}: waves that cooperate on one 16x16 tile (a lane owns 4 / waves pixels);
- *   "blend_bwd_reduce" in {0, 1, 2}: cross-lane reduction of the backward: DPP / permlane on the VALU (default), MFMA on the
- *       folded rows, or the transposed MFMA contraction (documented experiments: slower on gfx950);
+ *   "blend_bwd_reduce" in {0, 1, 2, 3}: cross-lane reduction of the backward: 3 = two hops through LDS (default: the per-Gaussian
+ *       sums of a quadrant are formed by reader lanes from transposed (r, w) pairs; plain-pass only, other configurations use 0),
+ *       0 = v_permlane swaps + DPP on the VALU, 1 = MFMA on the folded rows, 2 = transposed MFMA contraction (1 and 2 are
+ *       documented experiments: slower on gfx950);
  *   "bucket_hist" in {0, 1}: tile-bucket counting without global atomics (per-workgroup LDS histograms + a dense prefix table,
  *       default) or with one returning global atomic per instance (also taken for tile grids beyond 8192 tiles);
  *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the atomic variant;

@@ -32,7 +32,7 @@ SH_F32, SH_F16 = 0, 1  # sh_dtype of the _ex entry points
 N_EXTRA = 18  # extra feature channels of the fused multi-feature blend (six RGB triples)
 DEFAULT_BINNING = BINNING_TILE_BUCKET
 DEFAULT_TILE_CULL = 1  # tuning knob "tile_cull": exact ellipse-vs-tile culling in the tile-bucket back-end
-DEFAULT_BWD_REDUCE = 0
+DEFAULT_BWD_REDUCE = 3
 
 
 class GsrError(RuntimeError):

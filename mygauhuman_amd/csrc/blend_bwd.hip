@@ -105,13 +105,22 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   // colour sums are kept (6 values instead of 9); after the folds one row_ror-8 step turns them into COLUMN sums, the
   // x-weights (dx is a function of lx alone) are applied there, two values are packed into the two half rows, and three DPP
   // steps over 8 lanes finish: 18 permlane swaps + 19 DPP per four Gaussians instead of 27 + 36.
-  constexpr bool SEP = (SLOTS == 1 && RED == 0);
+  // LFOLD (RED == 3, one pixel per lane, no feature channels): the first two fold levels go through LDS instead of
+  // v_permlane32/16_swap.  A pixel lane leaves (r, w) of the group's four Gaussians in LDS (two 16-byte stores); lane
+  // (row = Gaussian, c = lane & 15) reads back the four pixels c + 16 q (same column, rows 2 q + (c >> 3)) of ITS Gaussian and
+  // forms the column-partial sums directly, with the y-weights as plain multiplies (ly is known per read) and the colour sums as
+  // w . dL_dpix of those four pixels (12 per-lane constants).  13 swaps (~4.2 FMA slots each), the register copies the swaps
+  // force and the hierarchical y-moment algebra are replaced by ~30 plain VALU instructions; the 8-lane tail is unchanged.
+  constexpr bool LFOLD = (SLOTS == 1 && RED == 3 && CE == 0);
+  constexpr bool SEP = (SLOTS == 1 && (RED == 0 || RED == 3));
   // HIER (with SEP): only sum r is kept per lane; with ly = 4 b2 + 2 b1 + b0 the folds over b2, b1, b0 also hand back their
   // "bit set" halves, so that  sum r ly = 4 E[b2] + 2 E[b1] + E[b0]  and  sum r ly^2 = 16 E[b2] + 4 E[b1] + E[b0] + 16 E[b2 b1]
   // + 8 E[b2 b0] + 4 E[b1 b0]  come out of 4 swaps instead of 9, and the moments about the Gaussian follow from
   // dy = Dy - ly (Dy = mean.y - top row of the quadrant).
-  constexpr bool HIER = SEP;
-  constexpr int NA = SEP ? (HIER ? 4 : 6) : NACC;
+  constexpr bool HIER = SEP && !LFOLD;
+  constexpr int NA = LFOLD ? 2 : (SEP ? (HIER ? 4 : 6) : NACC);
+  constexpr int LROW = 12;  // floats per pixel lane in the transposition buffer: 4 x (r, w) + 4 pad (conflict-free b64 reads)
+  __shared__ __attribute__((aligned(16))) float s_rw[LFOLD ? WAVE * LROW : 4];
   __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
@@ -188,6 +197,23 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   // an extra-colour column is live only if its triple is in the mask
   const bool onA = colA < NACC || ((a.extra_mask >> ((colA - NACC) / 3)) & 1u);
   const bool onB = colB != 0xFF && ((a.extra_mask >> ((colB - NACC) / 3)) & 1u);
+  float dps[LFOLD ? 4 : 1][3];  // LFOLD: dL_dpix of the four pixels (lane & 15) + 16 q this lane sums as a reader
+  if constexpr (LFOLD) {
+    s_rw[lane * 4 + 0] = dpix0[0];
+    s_rw[lane * 4 + 1] = dpix1[0];
+    s_rw[lane * 4 + 2] = dpix2[0];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 t4 = *reinterpret_cast<const float4 *>(&s_rw[((lane & 15) + 16 * q) * 4]);
+      dps[q][0] = t4.x;
+      dps[q][1] = t4.y;
+      dps[q][2] = t4.z;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 
   for (int base = skip; base < n; base += WAVE) {
     // ---- fetch 64 entries (from the back), cull, compact into LDS in back-to-front order
@@ -284,7 +310,10 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
               // moments of r = G * dL_dalpha over the pixels; preprocess_bwd.hip turns them into dL_dmean2D / dL_dconic
               const float r = G * dL_dalpha;
               float v[NA];
-              if constexpr (SEP && HIER) {
+              if constexpr (LFOLD) {
+                v[0] = r;
+                v[1] = w;
+              } else if constexpr (SEP && HIER) {
                 v[0] = r;  // the x- and y-weights are applied after the folds
                 v[1] = w * dpix0[s];
                 v[2] = w * dpix1[s];
@@ -326,14 +355,47 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
         }
       }
       if (anyhit) {  // wave-uniform
-        const int u_of_row = ((row & 1) << 1) | (row >> 1);  // after the folds row 0/1/2/3 = Gaussian g+0 / g+2 / g+1 / g+3
+        // after the swap folds row 0/1/2/3 = Gaussian g+0 / g+2 / g+1 / g+3; the LDS transposition reads row r = Gaussian g + r
+        const int u_of_row = LFOLD ? row : (((row & 1) << 1) | (row >> 1));
         const bool row_live = ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
         const uint32_t gid = row_live ? s_id[g + u_of_row] : 0u;
         if constexpr (SEP) {
           const float2 gxy = *reinterpret_cast<const float2 *>(&s0[g + u_of_row]);  // this row's Gaussian centre
           const float dxr = gxy.x - pxf[0];                // against this lane's column
           float qa, qb, qc, ka, kb;
-          if constexpr (HIER) {
+          if constexpr (LFOLD) {
+            *reinterpret_cast<float4 *>(&s_rw[lane * LROW]) = make_float4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+            *reinterpret_cast<float4 *>(&s_rw[lane * LROW + 4]) = make_float4(acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float2 rw[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rw[q] = *reinterpret_cast<const float2 *>(&s_rw[((int)(lane & 15) + 16 * q) * LROW + 2 * row]);
+            __builtin_amdgcn_wave_barrier();  // the next group's stores stay behind these reads
+            // this lane's four pixels: column lx = lane & 7, rows ly = 2 q + h, h = (lane >> 3) & 1
+            const float h = upper ? 1.f : 0.f;
+            const float e0 = (rw[0].x + rw[1].x) + (rw[2].x + rw[3].x);
+            const float A1 = rw[1].x + 2.f * rw[2].x + 3.f * rw[3].x;   // sum q r
+            const float A2 = rw[1].x + 4.f * rw[2].x + 9.f * rw[3].x;   // sum q^2 r
+            const float s1 = 2.f * A1 + h * e0;                         // sum ly r
+            const float s2 = 4.f * A2 + h * (4.f * A1 + e0);            // sum ly^2 r   (h^2 = h)
+            const float Dy = gxy.y - (pyf[0] - (float)(lane >> 3));     // mean.y - top pixel row of the quadrant
+            float c[6];
+            c[0] = e0;
+            c[1] = Dy * e0 - s1;                        // partial column sum of r dy
+            c[2] = Dy * (Dy * e0 - 2.f * s1) + s2;      // partial column sum of r dy^2
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+              c[3 + ch] = (rw[0].y * dps[0][ch] + rw[1].y * dps[1][ch]) + (rw[2].y * dps[2][ch] + rw[3].y * dps[3][ch]);
+            // from here on exactly the state the swap folds leave: lane j of a row holds the sums over its four rows of column j & 7
+            qa = pack_halves(c[0], c[1], upper);
+            qb = qa * dxr;
+            const float c2 = c[2] + dpp_f<0x128>(c[2]);
+            qc = upper ? c2 : qb * dxr;
+            ka = pack_halves(c[3], c[4], upper);
+            kb = c[5] + dpp_f<0x128>(c[5]);
+          } else if constexpr (HIER) {
             float a1ab, a1cd, b1, d1;
             const float a0ab = fold32_parts(acc[0][0], acc[1][0], a1ab), a0cd = fold32_parts(acc[2][0], acc[3][0], a1cd);
             const float b0 = fold16_parts(a0ab, a0cd, b1);  // sum over b2, b1      | b1 = 1 part
@@ -368,6 +430,31 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
             ka = pack_halves(c[NA - 3], c[NA - 2], upper);  // lower: red              upper: green
             kb = c[NA - 1] + dpp_f<0x128>(c[NA - 1]);       // blue in both halves
           }
+          if constexpr (LFOLD) {
+            // second LDS hop instead of 5 x 3 DPP steps + a select chain: lane (row, half, jx) leaves its five half-row values as
+            // [row][half][value][jx]; lane (row, column k < 9) reads the eight jx of ITS (half, value) -- two 16-byte loads -- adds them
+            // and owns column k of the Gaussian's gradient row, which is the layout the atomic wants
+            float *t2 = &s_rw[((row * 2 + (upper ? 1 : 0)) * 5) * 8 + jj];
+            t2[0] = qa;
+            t2[8] = qb;
+            t2[16] = qc;
+            t2[24] = ka;
+            t2[32] = kb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // column k: 0 r dx (lower qb) 1 r dy (upper qa) 2 r dx^2 (lower qc) 3 r dx dy (upper qb) 4 r dy^2 (upper qc)
+            //           5 r (lower qa)    6 red (lower ka)  7 green (upper ka)   8 blue (lower kb)
+            constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;                  // bit k: upper half
+            constexpr uint64_t VAL_OF_K = 0x0000000433021201ull >> 0;              // nibble k: which of qa..kb (0..4)
+            const int k9 = kcol < 9 ? kcol : 0;
+            const int hk = (int)((HALF_OF_K >> k9) & 1u), vk = (int)((VAL_OF_K >> (4 * k9)) & 0xFu);
+            const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2 + hk) * 5 + vk) * 8]);
+            const float4 lo4 = src8[0], hi4 = src8[1];
+            __builtin_amdgcn_wave_barrier();  // the next group's (r, w) stores stay behind these reads
+            const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
+            if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], vsum);
+          } else {
           qa = half8_sum(qa);
           qb = half8_sum(qb);
           qc = half8_sum(qc);
@@ -421,6 +508,7 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
               if (onB) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + colB], v1);
             }
           }
+          }  // !LFOLD
         } else {
         // four Gaussians x nine values reduced together
         float v;
@@ -706,6 +794,10 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
       return GSR_EINVAL;
     }
     hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    return GSR_OK;
+  }
+  if (opt.blend_bwd_reduce == 3 && opt.blend_bwd_waves == 4) {
+    hipLaunchKernelGGL((blend_backward_kernel<1, 3, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
   if (opt.blend_bwd_reduce == 2 && opt.blend_bwd_waves == 4) {

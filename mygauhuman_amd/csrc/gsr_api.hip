@@ -81,7 +81,7 @@ static int set_option(Options &o, const char *key, int v) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.tile_cull = v;
   } else if (!strcmp(key, "blend_bwd_reduce")) {
-    if (v < 0 || v > 2) return bad("0 (DPP), 1 (MFMA on folded rows) or 2 (transposed MFMA contraction)");
+    if (v < 0 || v > 3) return bad("0 (permlane / DPP folds), 1 (MFMA on folded rows), 2 (transposed MFMA contraction) or 3 (LDS folds)");
     o.blend_bwd_reduce = v;
   } else if (!strcmp(key, "deterministic")) {
     if (v != 0 && v != 1) return bad("0 or 1");

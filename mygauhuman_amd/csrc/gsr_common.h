@@ -157,7 +157,7 @@ struct Options {
   int bucket_cstride = 4;    // counters per 64-byte line = 16 / stride (interleaved A/B at C3, us of binning: 1: 112, 2: 106, 4: 100, 16: 126)
   int blend_fwd_waves = 4;   // waves that cooperate on one 16x16 tile
   int blend_bwd_waves = 4;
-  int blend_bwd_reduce = 0;  // 0 DPP / permlane, 1 MFMA on folded rows, 2 transposed MFMA contraction
+  int blend_bwd_reduce = 3;  // 3 LDS folds (default), 0 permlane / DPP folds, 1 MFMA on folded rows, 2 transposed MFMA contraction
   int deterministic = 0;     // backward: fixed-order reduction of the gradient rows instead of float atomics
 };
 Options options_for(hipStream_t stream);

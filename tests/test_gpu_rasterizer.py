@@ -23,9 +23,9 @@ def _bg(seed):
     return np.random.default_rng(seed + 5).uniform(0, 1, 3).astype(np.float32)
 
 
-@pytest.fixture(scope="module", params=[(1, 0), (2, 0), (4, 0), (4, 1), (2, 1), (4, 2)], ids=lambda p: f"waves{p[0]}red{p[1]}")
+@pytest.fixture(scope="module", params=[(1, 0), (2, 0), (4, 0), (4, 1), (2, 1), (4, 2), (4, 3)], ids=lambda p: f"waves{p[0]}red{p[1]}")
 def waves(request):
-    """(waves per tile, backward reduction: 0 = DPP rows, 1 = MFMA on folded rows, 2 = transposed MFMA contraction)"""
+    """(waves per tile, backward reduction: 0 = DPP rows, 1 = MFMA on folded rows, 2 = transposed MFMA contraction, 3 = LDS folds)"""
     from mygauhuman_amd import _lib
     w, red = request.param
     _lib.set_tuning("blend_fwd_waves", w)

@@ -15,19 +15,21 @@ def test_ssim_matches_reference_formulation(shape):
     g = torch.Generator().manual_seed(sum(shape))
     img2 = torch.rand(shape, generator=g).cuda()
     img1 = (img2 + 0.2 * torch.randn(shape, generator=g).cuda()).clamp(0, 1).requires_grad_(True)
-    ref1 = img1.detach().clone().requires_grad_(True)
+    # the conv2d formulation is evaluated on the CPU (fp32, then fp64): no MIOpen / device conv kernels in the checker
+    ref1 = img1.detach().cpu().clone().requires_grad_(True)
+    img2c = img2.cpu()
     v = loss_utils.ssim(img1, img2)
-    r = ssim_torch(ref1 if ref1.dim() == 4 else ref1[None], img2 if img2.dim() == 4 else img2[None])
+    r = ssim_torch(ref1 if ref1.dim() == 4 else ref1[None], img2c if img2c.dim() == 4 else img2c[None])
     assert abs(float(v.detach()) - float(r.detach())) < 2e-6
     (1.0 - v).backward()
     (1.0 - r).backward()
     scale = float(ref1.grad.abs().max())
-    assert float((img1.grad - ref1.grad).abs().max()) < 1e-4 * scale
+    assert float((img1.grad.cpu() - ref1.grad).abs().max()) < 1e-4 * scale
     # float64 check of the gradient
-    d1 = img1.detach().double().requires_grad_(True)
-    r64 = ssim_torch(d1 if d1.dim() == 4 else d1[None], (img2 if img2.dim() == 4 else img2[None]).double())
+    d1 = img1.detach().cpu().double().requires_grad_(True)
+    r64 = ssim_torch(d1 if d1.dim() == 4 else d1[None], (img2c if img2c.dim() == 4 else img2c[None]).double())
     (1.0 - r64).backward()
-    assert float((img1.grad.double() - d1.grad).abs().max()) < 2e-5 * scale
+    assert float((img1.grad.cpu().double() - d1.grad).abs().max()) < 2e-5 * scale
 
 
 def test_ssim_per_image_mode_identical_images_and_fallbacks():
@@ -37,8 +39,8 @@ def test_ssim_per_image_mode_identical_images_and_fallbacks():
     assert per.shape == (2,) and torch.allclose(per, torch.ones(2, device="cuda"), atol=1e-6)
     y = (x + 0.1).clamp(0, 1)
     a = loss_utils.ssim(x, y, size_average=False)
-    b = ssim_torch(x, y, size_average=False)
-    assert torch.allclose(a, b, atol=2e-6)
+    b = ssim_torch(x.cpu(), y.cpu(), size_average=False)
+    assert torch.allclose(a.cpu(), b, atol=2e-6)
     # no silent fallbacks: other window sizes and CPU tensors are refused
     with pytest.raises(RuntimeError):
         loss_utils.ssim(x, y, window_size=7)
