@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
 //   (tile scan as before: ranges / start)
 //   scatter : flat over the instances of a workgroup, no expansion: slot = start[tile] + table[workgroup][tile] + rank
 // The arrival order inside a tile is as arbitrary as with atomics; the per-tile sort makes the result deterministic.
-constexpr int HG = 2;                  // preprocess blocks per histogram workgroup
+constexpr int HG = 4;                  // preprocess blocks per histogram workgroup
 constexpr int HB = HG * PRE_BLOCK;     // Gaussians (= threads) per histogram workgroup
 constexpr int HIST_MAX_TILES = 8192;   // LDS counters: 32 KB (larger tile grids take the atomic path)
 __device__ __forceinline__ int pre_blocks_dev(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
@@ -375,8 +375,87 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t *b, int n, uint32_
 
 constexpr int SORT_WAVE_MAX = 1024;  // longest list handled by the register sort (16 keys per lane)
 
+// ---- sort by runs + rank merge (lists of 65 .. 512 keys) ---------------------------------------------------------------
+// A full bitonic network over NREG x 64 keys costs log^2 stages over every register and needs a power-of-two size: a tile with
+// 260 keys pays for 512.  Here every register is sorted ACROSS THE LANES as its own run of 64 (21 stages, all runs in lockstep),
+// the runs go to LDS, and each key finds its final position as  lane + sum over the other runs of (keys smaller than it)  by a
+// binary search per run (keys are unique: they contain the Gaussian id).  Work grows with the number of runs actually needed
+// (5 runs for 260 keys), not with the next power of two; at C3 (lists of ~240, up to 355) this is ~2x fewer instructions.
+constexpr int MERGE_MAX_RUNS = 8;
+
+template <int J>
+__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v) {
+  uint32_t lo, hi;
+  if constexpr (J < 32) {  // ds_swizzle bit-mode: lane ^ J inside each group of 32
+    lo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)v, (J << 10) | 0x1F);
+    hi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)(v >> 32), (J << 10) | 0x1F);
+  } else {
+    lo = (uint32_t)__shfl_xor((int)(uint32_t)v, J, WAVE);
+    hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), J, WAVE);
+  }
+  return ((uint64_t)hi << 32) | lo;
+}
+// one compare-exchange stage (block size K, distance J) of an ASCENDING bitonic sort of 64 keys held one per lane
+template <int NRUN, int K, int J>
+__device__ __forceinline__ void run_stage(uint64_t (&key)[NRUN], uint32_t lane) {
+  const bool take_min = ((lane & (uint32_t)J) == 0) == ((lane & (uint32_t)K) == 0 || K == WAVE);
+#pragma unroll
+  for (int r = 0; r < NRUN; r++) {
+    const uint64_t mine = key[r], other = lane_xor_u64<J>(mine);
+    key[r] = take_min ? (mine < other ? mine : other) : (mine > other ? mine : other);
+  }
+}
+template <int NRUN, int K, int J>
+__device__ __forceinline__ void run_merge(uint64_t (&key)[NRUN], uint32_t lane) {
+  run_stage<NRUN, K, J>(key, lane);
+  if constexpr (J > 1) run_merge<NRUN, K, J / 2>(key, lane);
+}
+template <int NRUN, int K>
+__device__ __forceinline__ void run_levels(uint64_t (&key)[NRUN], uint32_t lane) {
+  run_merge<NRUN, K, K / 2>(key, lane);
+  if constexpr (K < WAVE) run_levels<NRUN, K * 2>(key, lane);
+}
+
+template <int NRUN>
+__device__ __forceinline__ void wave_sort_tile_runs(const uint64_t *b, int n, uint32_t tile, uint32_t base, uint32_t *point_list,
+                                                    uint64_t *keys_sorted, uint32_t lane, uint64_t *s_runs) {
+  uint64_t key[NRUN];
+#pragma unroll
+  for (int r = 0; r < NRUN; r++) {
+    const int i = r * WAVE + (int)lane;
+    key[r] = i < n ? b[i] : ~0ull;  // padding sorts behind every real key and is never stored
+  }
+  run_levels<NRUN, 2>(key, lane);  // every register: one ascending run of 64 across the lanes
+#pragma unroll
+  for (int r = 0; r < NRUN; r++) s_runs[r * WAVE + (int)lane] = key[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int r = 0; r < NRUN; r++) {
+    const uint64_t k = key[r];
+    uint32_t rank = lane;      // keys of its own run in front of it
+#pragma unroll
+    for (int o = 0; o < NRUN; o++) {
+      if (o == r) continue;
+      const uint64_t *run = s_runs + o * WAVE;
+      // branch-free: the searches of a key in the other runs (and of the lane's other keys) are independent chains of LDS
+      // reads the scheduler can overlap
+      uint32_t c = 0u;
+#pragma unroll
+      for (int step = WAVE / 2; step >= 1; step >>= 1) c += run[c + step - 1] < k ? (uint32_t)step : 0u;
+      rank += run[WAVE - 1] < k ? (uint32_t)WAVE : c;  // whole run smaller?
+    }
+    if (k != ~0ull) {  // not padding
+      point_list[base + rank] = (uint32_t)k;
+      keys_sorted[base + rank] = ((uint64_t)tile << 32) | (k >> 32);
+    }
+  }
+}
+
 __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ranges, const uint64_t *bucket, uint32_t *point_list,
                                                                uint64_t *keys_sorted) {
+  __shared__ uint64_t s_runs[MERGE_MAX_RUNS * WAVE];
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const uint2 r = ranges[tile];
   const int n = (int)(r.y - r.x);
@@ -385,11 +464,17 @@ __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ran
   if (n <= 64)
     wave_sort_tile<1>(b, n, tile, r.x, point_list, keys_sorted, lane);
   else if (n <= 128)
-    wave_sort_tile<2>(b, n, tile, r.x, point_list, keys_sorted, lane);
+    wave_sort_tile_runs<2>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
+  else if (n <= 192)
+    wave_sort_tile_runs<3>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
   else if (n <= 256)
-    wave_sort_tile<4>(b, n, tile, r.x, point_list, keys_sorted, lane);
+    wave_sort_tile_runs<4>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
+  else if (n <= 320)
+    wave_sort_tile_runs<5>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
+  else if (n <= 384)
+    wave_sort_tile_runs<6>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
   else if (n <= 512)
-    wave_sort_tile<8>(b, n, tile, r.x, point_list, keys_sorted, lane);
+    wave_sort_tile_runs<8>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
   else
     wave_sort_tile<16>(b, n, tile, r.x, point_list, keys_sorted, lane);
 }

@@ -123,8 +123,9 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   __shared__ __attribute__((aligned(16))) float s_rw[LFOLD ? WAVE * LROW : 4];
   __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
-  __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
-  __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
+  // (layout as in blend_fwd.hip: the cut-off test reads s0 + s1, a contributing survivor additionally s2: whole 16-byte reads)
+  __shared__ float4 s1[WAVE];     // qc, log2(255*opacity), front position (bits), opacity   (qc = -conic_c log2(e)/2)
+  __shared__ float4 s2[WAVE];     // r, g, b, depth
   __shared__ uint32_t s_id[WAVE + 4];
   __shared__ uint32_t s_slot[DET ? WAVE + 4 : 1];
 
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
       constexpr float L2E = 1.4426950408889634f;
       s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
-      s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
-      s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)));
+      s1[slot] = make_float4((-0.5f * L2E) * r1.x, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)), r1.y);
+      s2[slot] = make_float4(r1.w, r2.x, r2.y, r1.z);
       s_id[slot] = id;
       if constexpr (DET) {  // this instance's slot: same rectangle arithmetic as the preprocess (CR/auxiliary.h:46-56)
         int bx0, by0, bx1, by1;
@@ -278,24 +279,24 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
           const float4 g0 = s0[g + u];
           const float4 g1 = s1[g + u];
           const float4 g2 = s2[g + u];
-          const int fpos = (int)__float_as_uint(g2.w);  // 0-based position from the front
+          const int fpos = (int)__float_as_uint(g1.z);  // 0-based position from the front
 #pragma unroll
           for (int s = 0; s < SLOTS; s++) {
             const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
             const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
-            const bool pre = (fpos < lastc[s]) && !(p2 > 0.0f) && (p2 + g2.z >= -0.02f);
+            const bool pre = (fpos < lastc[s]) && !(p2 > 0.0f) && (p2 + g1.y >= -0.02f);
             if (__ballot(pre) != 0ull) {  // wave-uniform: some lane may reach alpha >= 1/255
               // Select form instead of an exec-masked block: on lanes that are not hit alpha and G are forced to zero, which
               // makes every update below an exact no-op (rc = 1, Tn = T, w = 0, r = 0) -- same results, no second ballot,
               // no mask save / restore, no zero-initialisation of the sums.
               const float G0 = __builtin_amdgcn_exp2f(p2);
-              const float alpha0 = fminf(0.99f, g1.y * G0);
+              const float alpha0 = fminf(0.99f, g1.w * G0);
               const bool hit = pre && !(alpha0 < 1.0f / 255.0f);
               const float alpha = hit ? alpha0 : 0.f, G = hit ? G0 : 0.f;
               const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
               const float Tn = T[s] * rc;  // transmittance in front of this Gaussian
               const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
-              float e = g1.w * dpix0[s] + g2.x * dpix1[s] + g2.y * dpix2[s] + g1.z * ddep[s] + dalp[s];
+              float e = g2.x * dpix0[s] + g2.y * dpix1[s] + g2.z * dpix2[s] + g2.w * ddep[s] + dalp[s];
               if (CE > 0) {
 #pragma unroll
                 for (int t = 0; t < CE / 3; t++)

@@ -31,8 +31,11 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   constexpr int WPT = 4 / SLOTS;  // waves per tile
   __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];  // survivors' extra channels
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
-  __shared__ float4 s1[WAVE];     // qc, opacity, depth, r   (qc = -conic_c log2(e)/2)
-  __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), list position + 1 (bits)
+  // what the cut-off test needs sits in s0 + the first half of s1, what only a blending survivor needs in the second half of s1 +
+  // s2: each branch's LDS reads are whole 8- / 16-byte accesses (a 4-byte broadcast read costs as many LDS cycles as an 8-byte one,
+  // and the kernel runs the LDS at ~2/3 of its cycles)
+  __shared__ float4 s1[WAVE];     // qc, log2(255*opacity) | list position + 1 (bits), opacity   (qc = -conic_c log2(e)/2)
+  __shared__ float4 s2[WAVE];     // r, g, b, depth
 
   const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t tile = item / WPT, part = item % WPT;
@@ -102,8 +105,8 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
       // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
       constexpr float L2E = 1.4426950408889634f;
       s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
-      s1[slot] = make_float4((-0.5f * L2E) * r1.x, r1.y, r1.z, r1.w);
-      s2[slot] = make_float4(r2.x, r2.y, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(idx + 1)));
+      s1[slot] = make_float4((-0.5f * L2E) * r1.x, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(idx + 1)), r1.y);
+      s2[slot] = make_float4(r1.w, r2.x, r2.y, r1.z);
       if (CE > 0) {
         const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
 #pragma unroll
@@ -124,26 +127,26 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
         const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
         const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
         // cheap necessary condition for alpha >= 1/255:  log2(255*o) + power*log2(e) >= 0  (0.02 safety margin)
-        const bool pre = !(p2 > 0.0f) && ((p2 + g2.z) + dbias[s] >= -0.02f);
+        const bool pre = !(p2 > 0.0f) && ((p2 + g1.y) + dbias[s] >= -0.02f);
         if (__ballot(pre) != 0ull) {
-          const float alpha = fminf(0.99f, g1.y * __builtin_amdgcn_exp2f(p2));
+          const float alpha = fminf(0.99f, g1.w * __builtin_amdgcn_exp2f(p2));
           const bool hit = pre && !(alpha < 1.0f / 255.0f);
           const float test_T = T[s] * (1.0f - alpha);
           const bool stop = hit && test_T < 0.0001f;
           const bool blend = hit && !stop;
           dbias[s] = stop ? -1e30f : dbias[s];
           const float w = blend ? alpha * T[s] : 0.0f;
-          C0[s] += g1.w * w;
-          C1[s] += g2.x * w;
-          C2[s] += g2.y * w;
-          Dp[s] += g1.z * w;
+          C0[s] += g2.x * w;
+          C1[s] += g2.y * w;
+          C2[s] += g2.z * w;
+          Dp[s] += g2.w * w;
           Wt[s] += w;
           if (CE > 0) {
 #pragma unroll
             for (int c = 0; c < CE; c++) X[s][c] += s_x[k * CE + c] * w;
           }
           T[s] = blend ? test_T : T[s];
-          last[s] = blend ? __float_as_uint(g2.w) : last[s];
+          last[s] = blend ? __float_as_uint(g1.z) : last[s];
         }
       }
     }

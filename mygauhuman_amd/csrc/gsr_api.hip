@@ -548,7 +548,8 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   float *det_rows = nullptr;
   const size_t det_bytes = (size_t)(R > 0 ? R : 1) * 4 * GROW * sizeof(float);
   if (opt.deterministic) {  // one 64-byte slot per (instance, quadrant), zeroed: culled instances keep zeros
-    GSR_HIP(hipMallocAsync(reinterpret_cast<void **>(&det_rows), det_bytes, stream));
+    // (a test mode: plain hipMalloc / hipFree around the call, no stream-ordered pool involved)
+    GSR_HIP(hipMalloc(reinterpret_cast<void **>(&det_rows), det_bytes));
     GSR_HIP(hipMemsetAsync(det_rows, 0, det_bytes, stream));
   } else {
     GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * grow * sizeof(float), stream));
@@ -584,8 +585,13 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   int rc = launch_blend_backward(ba, opt, stream);
   if (rc == GSR_OK && det_rows) rc = launch_reduce_det_rows(P, geom.point_offsets, geom.tiles_touched, det_rows, (size_t)(R > 0 ? R : 1) * 4, geom.grad_rows, stream);
   prof_end(PROF_BLEND_BWD, stream);
-  if (det_rows) (void)hipFreeAsync(det_rows, stream);
-  if (rc != GSR_OK) return rc;
+  if (rc != GSR_OK) {
+    if (det_rows) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipFree(det_rows);
+    }
+    return rc;
+  }
   GSR_LAUNCH_CHECK(stream, debug);
 
   PreprocessBwdArgs pb;
@@ -628,6 +634,10 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   prof_begin(PROF_PREPROCESS_BWD, stream);
   rc = launch_preprocess_backward(pb, stream);
   prof_end(PROF_PREPROCESS_BWD, stream);
+  if (det_rows) {  // deterministic (test) mode: the slots die with the call
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(det_rows);
+  }
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;
