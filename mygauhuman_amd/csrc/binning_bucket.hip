@@ -110,6 +110,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
 // The arrival order inside a tile is as arbitrary as with atomics; the per-tile sort makes the result deterministic.
 constexpr int HG = 4;                  // preprocess blocks per histogram workgroup
 constexpr int HB = HG * PRE_BLOCK;     // Gaussians (= threads) per histogram workgroup
+constexpr int HU = 2;                  // owner searches in flight per lane of the histogram kernel
 constexpr int HIST_MAX_TILES = 8192;   // LDS counters: 32 KB (larger tile grids take the atomic path)
 __device__ __forceinline__ int pre_blocks_dev(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
 
@@ -130,26 +131,41 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
   const int i = first + (int)threadIdx.x;
   const int b0 = blockIdx.x * HG, n_pre = pre_blocks_dev(P);
   for (int t = threadIdx.x; t < tiles; t += HB) s_cnt[t] = 0;
+  // this thread's Gaussian: issue the loads before the scan of the block sums so both latencies overlap
+  uint32_t incl_local = 0;
+  int rad = 0;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  if (i < P) {
+    incl_local = g.block_incl[i];
+    rad = radii[i];
+    r0 = reinterpret_cast<const float4 *>(g.recs + i)[0];
+    if (TIGHT) r1 = reinterpret_cast<const float4 *>(g.recs + i)[1];
+  }
   if (SCAN) {
+    // own = the sums of this workgroup's HG blocks (lanes 0..HG-1 of wave 0), part = everything in front of the workgroup
+    const uint32_t own = ((int)threadIdx.x < HG && b0 + (int)threadIdx.x < n_pre) ? g.block_sums[b0 + threadIdx.x] : 0u;
     uint32_t part = 0;
     for (int b = threadIdx.x; b < b0; b += HB) part += g.block_sums[b];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, WAVE);
     if (threadIdx.x % WAVE == 0) s_wsum[threadIdx.x / WAVE] = part;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t run = 0;
-      for (int w = 0; w < HB / WAVE; w++) run += s_wsum[w];
-      s_boff[0] = run;
-      uint32_t off = 0;
-      for (int k = 0; k < HG; k++) {
-        s_boff[1 + k] = off;
-        if (b0 + k < n_pre) {
-          g.block_prefix[b0 + k] = run + off;
-          off += g.block_sums[b0 + k];
-        }
+    if (threadIdx.x < WAVE) {
+      uint32_t run = (int)threadIdx.x < HB / WAVE ? s_wsum[threadIdx.x] : 0u;
+#pragma unroll
+      for (int d = HB / WAVE / 2; d >= 1; d >>= 1) run += __shfl_xor(run, d, WAVE);
+      uint32_t off = own;  // inclusive scan over the HG lanes
+#pragma unroll
+      for (int d = 1; d < HG; d <<= 1) {
+        const uint32_t up = __shfl_up(off, d, WAVE);
+        if ((int)threadIdx.x >= d) off += up;
       }
-      if (blockIdx.x == gridDim.x - 1) g.total[0] = run + off;  // the last workgroup holds the last blocks: this is R
+      if ((int)threadIdx.x < HG) {
+        s_boff[1 + threadIdx.x] = off - own;
+        if (b0 + (int)threadIdx.x < n_pre) g.block_prefix[b0 + threadIdx.x] = run + off - own;
+      }
+      if (threadIdx.x == 0) s_boff[0] = run;
+      if ((int)threadIdx.x == HG - 1 && blockIdx.x == gridDim.x - 1) g.total[0] = run + off;  // the last blocks: this is R
     }
     __syncthreads();
   } else {
@@ -164,16 +180,13 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
   uint32_t incl = 0xFFFFFFFFu, rect = 0;
   if (i < P) {
     // inclusive scan of tiles_touched inside this workgroup = block-local scan + the block's offset inside the group
-    incl = g.block_incl[i] + s_boff[1 + threadIdx.x / PRE_BLOCK];
+    incl = incl_local + s_boff[1 + threadIdx.x / PRE_BLOCK];
     g.point_offsets[i] = sb_prefix + incl;
-    const int rad = radii[i];
     if (rad > 0) {
-      const float4 r0 = reinterpret_cast<const float4 *>(g.recs + i)[0];
       int x0, y0, x1, y1;
       tile_rect(r0.x, r0.y, rad, gx, gy, x0, y0, x1, y1);
       rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
       if (TIGHT) {
-        const float4 r1 = reinterpret_cast<const float4 *>(g.recs + i)[1];
         s_geo[threadIdx.x] = r0;
         s_geo2[threadIdx.x] = make_float2(r1.x, r1.y);
       }
@@ -184,33 +197,48 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
   __syncthreads();
   const int nvalid = min(HB, P - first);
   const uint32_t total = s_incl[nvalid - 1];
-  for (uint32_t k = threadIdx.x; k < total; k += HB) {
-    int lo = 0, hi = nvalid - 1;  // first j with incl[j] > k
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (s_incl[mid] > k)
-        hi = mid;
-      else
-        lo = mid + 1;
+  // owner search: branch-free descent over the inclusive scan (entries past nvalid hold 0xFFFFFFFF), HU instances per lane in
+  // flight so the dependent LDS reads of one search hide behind the other's
+  for (uint32_t k0 = threadIdx.x; k0 < total; k0 += HB * HU) {
+    uint32_t kk[HU];
+    int own[HU];
+#pragma unroll
+    for (int u = 0; u < HU; u++) {
+      kk[u] = k0 + (uint32_t)u * HB;
+      own[u] = 0;
     }
-    const uint32_t start = lo == 0 ? 0u : s_incl[lo - 1];
-    const uint32_t local = k - start;
-    const uint32_t rc = s_rect[lo];
-    const uint32_t w = rc >> 20, x0 = rc & 1023u, y0 = (rc >> 10) & 1023u;
-    const uint32_t ty = y0 + local / w, tx = x0 + local % w;
-    bool keep = true;
-    if (TIGHT) {
-      const float4 ge = s_geo[lo];
-      const float2 g2 = s_geo2[lo];
-      const float px0 = (float)(tx * TILE), py0 = (float)(ty * TILE);
-      keep = ellipse_hits_rect(ge.x, ge.y, ge.z, ge.w, g2.x, g2.y, px0, px0 + (float)(TILE - 1), py0, py0 + (float)(TILE - 1));
+#pragma unroll
+    for (int step = HB / 2; step >= 1; step >>= 1) {
+#pragma unroll
+      for (int u = 0; u < HU; u++) {
+        const int idx = own[u] + step;
+        if (s_incl[idx - 1] <= kk[u]) own[u] = idx;  // own = number of Gaussians that end at or before instance kk
+      }
     }
-    const uint32_t tile = ty * (uint32_t)gx + tx;
-    const uint32_t r = keep ? ((tile << 16) | atomicAdd(&s_cnt[tile], 1u)) : CULLED_INSTANCE;  // LDS returning add, rank < HB
-    const uint32_t inst = sb_prefix + k;
-    if (inst < capacity) {
-      rank[inst] = r;
-      gids[inst] = (uint32_t)(first + lo);
+#pragma unroll
+    for (int u = 0; u < HU; u++) {
+      const uint32_t k = kk[u];
+      if (k >= total) continue;
+      const int lo = own[u];
+      const uint32_t start = lo == 0 ? 0u : s_incl[lo - 1];
+      const uint32_t local = k - start;
+      const uint32_t rc = s_rect[lo];
+      const uint32_t w = rc >> 20, x0 = rc & 1023u, y0 = (rc >> 10) & 1023u;
+      const uint32_t ty = y0 + local / w, tx = x0 + local % w;
+      bool keep = true;
+      if (TIGHT) {
+        const float4 ge = s_geo[lo];
+        const float2 g2 = s_geo2[lo];
+        const float px0 = (float)(tx * TILE), py0 = (float)(ty * TILE);
+        keep = ellipse_hits_rect(ge.x, ge.y, ge.z, ge.w, g2.x, g2.y, px0, px0 + (float)(TILE - 1), py0, py0 + (float)(TILE - 1));
+      }
+      const uint32_t tile = ty * (uint32_t)gx + tx;
+      const uint32_t r = keep ? ((tile << 16) | atomicAdd(&s_cnt[tile], 1u)) : CULLED_INSTANCE;  // LDS returning add, rank < HB
+      const uint32_t inst = sb_prefix + k;
+      if (inst < capacity) {
+        rank[inst] = r;
+        gids[inst] = (uint32_t)(first + lo);
+      }
     }
   }
   __syncthreads();
@@ -482,14 +510,12 @@ __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ran
 // CAP = LDS capacity in keys; the instantiation handles tiles with LO < n <= CAP (the big one also n > CAP).  Two
 // launches (1024 / 8192 keys) keep the common short lists at 8 KB of LDS per workgroup = full occupancy.
 template <int CAP, int LO, bool TAKES_OVERSIZE>
-__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, uint64_t *bucket, uint32_t *point_list,
-                                                         uint64_t *keys_sorted) {
+__device__ __forceinline__ void sort_big_tile(uint32_t tile, uint64_t *s_keys, const uint2 *ranges, uint64_t *bucket,
+                                              uint32_t *point_list, uint64_t *keys_sorted) {
   constexpr int SORT_LDS_MAX = CAP;
-  __shared__ uint64_t s_keys[CAP];
-  const uint32_t tile = blockIdx.x;
   const uint2 r = ranges[tile];
   const int n = (int)(r.y - r.x);
-  if (n <= LO || (!TAKES_OVERSIZE && n > CAP)) return;
+  if (n <= LO || (!TAKES_OVERSIZE && n > CAP)) return;  // (the same for every thread of the workgroup)
   uint64_t *b = bucket + r.x;
   if (n <= SORT_LDS_MAX) {
     int np = 1;
@@ -566,6 +592,28 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
       point_list[r.x + i] = (uint32_t)k;
       keys_sorted[r.x + i] = ((uint64_t)tile << 32) | (k >> 32);
     }
+  }
+}
+
+// Lists longer than SORT_WAVE_MAX are rare (none at C3), so the workgroups stride over the tiles instead of one launch slot
+// per tile: a grid of a few hundred workgroups skims the ranges (5 us of empty workgroups before) and sorts what it finds.
+template <int CAP, int LO, bool TAKES_OVERSIZE>
+__global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, uint64_t *bucket, uint32_t *point_list,
+                                                         uint64_t *keys_sorted, uint32_t n_tiles) {
+  __shared__ uint64_t s_keys[CAP];
+  __shared__ int s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  // one round of independent loads over this workgroup's tiles: is there anything to do at all?
+  for (uint32_t t = blockIdx.x + threadIdx.x * gridDim.x; t < n_tiles; t += 256u * gridDim.x) {
+    const uint2 r = ranges[t];
+    if ((int)(r.y - r.x) > LO) s_any = 1;
+  }
+  __syncthreads();
+  if (!s_any) return;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    sort_big_tile<CAP, LO, TAKES_OVERSIZE>(tile, s_keys, ranges, bucket, point_list, keys_sorted);
+    __syncthreads();  // s_keys is reused by the next tile
   }
 }
 
@@ -646,8 +694,8 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   GSR_LAUNCH_CHECK(stream, debug);
   // (a separate 16 KB-LDS instantiation for 1025..2048 keys was measured: slower -- the register sorts of the runs, not the
   // LDS occupancy, bound this kernel)
-  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)tiles), dim3(256), 0, stream, ranges,
-                     b.keys_a, b.vals_s, b.keys_s);
+  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(256), 0,
+                     stream, ranges, b.keys_a, b.vals_s, b.keys_s, (uint32_t)tiles);
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;
 }
