@@ -4,6 +4,7 @@ render hot path, with the reference's method names and semantics (scene/gaussian
     training_setup :250-287 (Adam groups by name)      add_densification_stats :764-766    reset_opacity :348-351
     prune_points :443-461                              densify_and_clone :544-565          densify_and_split :514-542
     densify_and_prune :697-726 (clone, split, then prune by opacity / screen size / world size / distance to the SMPL surface)
+    kl_div :740-762, kl_densify_and_clone :566-606, kl_densify_and_split :608-666, kl_merge :668-708 (pairs from the k = 2 self k-NN)
 
 What changes underneath: the reference rebuilds 9 parameters x (value, exp_avg, exp_avg_sq) + 3 statistics with boolean-mask
 indexing and torch.cat -- about 90 kernels and 30 host synchronisations per operation.  Here every operation is ONE row plan
@@ -174,11 +175,10 @@ def densify_and_clone(model, grads, grad_threshold, scene_extent):
     return sel
 
 
-def densify_and_split(model, grads, grad_threshold, scene_extent, N=2, unit_samples=None):
-    """unit_samples: optional N(0,1) draws [N * n_selected, 3] (tests); default torch.randn like the reference's torch.normal."""
-    P = model._xyz.shape[0]
+def _split_selected(model, sel, N, unit_samples):
+    """The body shared by densify_and_split (:527-542) and kl_densify_and_split (:649-666): every selected Gaussian is replaced
+    by N children drawn from it, 1 / (0.8 N) of its size."""
     scal = model.get_scaling.detach()
-    sel = split_mask(grads, P, scal, grad_threshold, scene_extent, model.percent_dense)
     plan, children, first = plan_split(sel, N)
     n_child = int(children.shape[0])
     if n_child:
@@ -194,6 +194,105 @@ def densify_and_split(model, grads, grad_threshold, scene_extent, N=2, unit_samp
         with torch.no_grad():
             model._xyz[first:] = new_xyz
             model._scaling[first:] = new_scaling
+
+
+def densify_and_split(model, grads, grad_threshold, scene_extent, N=2, unit_samples=None):
+    """unit_samples: optional N(0,1) draws [N * n_selected, 3] (tests); default torch.randn like the reference's torch.normal."""
+    sel = split_mask(grads, model._xyz.shape[0], model.get_scaling.detach(), grad_threshold, scene_extent, model.percent_dense)
+    _split_selected(model, sel, N, unit_samples)
+    return sel
+
+
+# ---------------------------------------------------------------- KL-divergence variants (scene/gaussian_model.py:566-708,740-762)
+# Not called by the reference's own training loop (its densify_and_prune has them commented out, :702-704), kept here with the
+# reference's names and thresholds for callers that enable them.  The pair of every Gaussian is (itself, its nearest other
+# Gaussian) from the self k-NN with k = 2 (gsr_knn_self instead of KNN_CUDA).
+def kl_div(mu_0, rotation_0_q, scaling_0_diag, mu_1, rotation_1_q, scaling_1_diag):
+    """KL( N(mu_0, S_0) || N(mu_1, S_1) ) = 1/2 [ tr(S_1^-1 S_0) + d^T S_1^-1 d + ln(det S_1 / det S_0) - 3 ],  S = R diag(s^2) R^T."""
+    R0, R1 = covariance.build_rotation(rotation_0_q), covariance.build_rotation(rotation_1_q)
+    cov_0 = covariance.bmm3(R0 * (scaling_0_diag * scaling_0_diag).unsqueeze(1), R0.transpose(1, 2))
+    inv_1 = covariance.bmm3(R1 * (1.0 / (scaling_1_diag * scaling_1_diag)).unsqueeze(1), R1.transpose(1, 2))
+    d = mu_1 - mu_0
+    trace = (inv_1 * cov_0).sum(dim=(1, 2))                       # both symmetric: tr(A B) = sum_ij A_ij B_ij
+    maha = (covariance.bmm3(inv_1, d.unsqueeze(2)).squeeze(2) * d).sum(1)
+    logdet = torch.log(torch.prod((scaling_1_diag / scaling_0_diag) ** 2, dim=1))
+    return 0.5 * (trace + maha + logdet - 3.0)
+
+
+def kl_to_nearest(model):
+    """(kl [P], ids [P, 2] int64): divergence between every Gaussian's k-NN pair (:573-589)."""
+    from .knn_cuda import knn_self
+    xyz = model._xyz.detach()
+    _, ids = knn_self(xyz, 2)
+    ids = ids.long()
+    rot, scal = model._rotation.detach(), model.get_scaling.detach()
+    i0, i1 = ids[:, 0], ids[:, 1]
+    return kl_div(xyz[i0], rot[i0], scal[i0], xyz[i1], rot[i1], scal[i1]), ids
+
+
+def kl_densify_and_clone(model, grads, grad_threshold, scene_extent, kl_threshold=0.4, unit_samples=None):
+    """:566-606.  Unlike densify_and_clone the copy is displaced by a draw from the Gaussian itself."""
+    sel = clone_mask(grads, model.get_scaling.detach(), grad_threshold, scene_extent, model.percent_dense)
+    kl, _ = kl_to_nearest(model)
+    model.kl_selected_pts_mask = kl > kl_threshold
+    sel = sel & model.kl_selected_pts_mask
+    src = torch.nonzero(sel, as_tuple=False).squeeze(1)
+    n_new, first = int(src.shape[0]), model._xyz.shape[0]
+    if n_new:
+        stds = model.get_scaling.detach()[src]
+        unit = torch.randn((n_new, 3), device=stds.device) if unit_samples is None else unit_samples[:n_new].to(stds.device)
+        rots = covariance.build_rotation(model._rotation.detach()[src])
+        new_xyz = covariance.bmm3(rots, (stds * unit).unsqueeze(-1)).squeeze(-1) + model._xyz.detach()[src]
+        new_scaling = torch.log(stds)                             # scaling_inverse_activation(get_scaling)
+    apply_plan(model, plan_clone(sel), reset_stats=True)
+    if n_new:
+        with torch.no_grad():
+            model._xyz[first:] = new_xyz
+            model._scaling[first:] = new_scaling
+    return sel
+
+
+def kl_densify_and_split(model, grads, grad_threshold, scene_extent, kl_threshold=0.4, N=2, unit_samples=None):
+    """:608-666."""
+    sel = split_mask(grads, model._xyz.shape[0], model.get_scaling.detach(), grad_threshold, scene_extent, model.percent_dense)
+    kl, _ = kl_to_nearest(model)
+    model.kl_selected_pts_mask = kl > kl_threshold
+    sel = sel & model.kl_selected_pts_mask
+    _split_selected(model, sel, N, unit_samples)
+    return sel
+
+
+def kl_merge(model, grads, grad_threshold, scene_extent, kl_threshold=0.1):
+    """:668-708: a selected small Gaussian whose pair is closer than kl_threshold is replaced, together with its partner, by one
+    Gaussian at their mean (position, SH, opacity averaged; rotation of the first, its scale / 0.8).
+
+    The reference's body cannot run as written: it averages `_normal[selected_pts_mask]` over the wrong axis and calls
+    densification_postfix with 7 of its 9 arguments (:694-698, a TypeError).  normal / albedo / roughness follow the rule of the
+    other averaged attributes here (mean over the pair)."""
+    P = model._xyz.shape[0]
+    padded = torch.zeros((P,), device=grads.device, dtype=grads.dtype)
+    padded[:grads.shape[0]] = grads.squeeze()
+    sel = torch.logical_and(padded >= grad_threshold,
+                            torch.max(model.get_scaling.detach(), dim=1).values <= model.percent_dense * scene_extent)
+    kl, ids = kl_to_nearest(model)
+    model.kl_selected_pts_mask = kl < kl_threshold
+    sel = sel & model.kl_selected_pts_mask
+    pair = ids[sel]                                               # [n, 2]
+    n_new = int(pair.shape[0])
+    if n_new == 0:
+        return sel
+    with torch.no_grad():
+        mean = {g: getattr(model, ATTR[g]).detach()[pair].mean(1) for g in GROUPS if g not in ("scaling", "rotation")}
+        new_scaling = torch.log(model.get_scaling.detach()[pair][:, 0] / 0.8)
+    gone = sel.clone()
+    gone[pair[:, 1]] = True
+    keep = torch.nonzero(~gone, as_tuple=False).squeeze(1).to(torch.int32)
+    first = int(keep.shape[0])
+    apply_plan(model, torch.cat([keep, pair[:, 0].to(torch.int32) | NEW_ROW]), reset_stats=True)   # rotation: copied from the first
+    with torch.no_grad():
+        for g, v in mean.items():
+            getattr(model, ATTR[g])[first:] = v
+        model._scaling[first:] = new_scaling
     return sel
 
 

@@ -122,3 +122,39 @@ def test_reset_opacity_and_stats_on_cpu_tensors():
     do.add_densification_stats(ref, vs.grad.numpy(), filt.numpy())
     np.testing.assert_allclose(m.xyz_gradient_accum.numpy(), ref["xyz_gradient_accum"], rtol=1e-6)
     np.testing.assert_array_equal(m.denom.numpy(), ref["denom"])
+
+
+def test_kl_div_known_answers_and_restatement():
+    """kl_div is plain tensor math (runs on CPU tensors): closed-form cases + the float64 numpy restatement of :740-762."""
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))  # noqa: E731
+    q_id = np.array([[1.0, 0, 0, 0]], np.float32)
+    one = np.ones((1, 3), np.float32)
+    z = np.zeros((1, 3), np.float32)
+    same = densify.kl_div(t(z), t(q_id), t(one), t(z), t(q_id), t(one))
+    assert abs(float(same)) < 1e-6
+    shifted = densify.kl_div(t(z), t(q_id), t(one), t([[0.3, -0.4, 1.2]]), t(q_id), t(one))     # 1/2 |d|^2
+    assert abs(float(shifted) - 0.5 * (0.09 + 0.16 + 1.44)) < 1e-6
+    wider = densify.kl_div(t(z), t(q_id), t(one), t(z), t(q_id), t(2 * one))                    # S1 = 4 I
+    assert abs(float(wider) - 0.5 * (0.75 + np.log(64.0) - 3.0)) < 1e-6
+    rng = np.random.default_rng(5)
+    n = 500
+    mu0, mu1 = rng.normal(0, 1, (n, 3)).astype(np.float32), rng.normal(0, 1, (n, 3)).astype(np.float32)
+    q0, q1 = rng.normal(0, 1, (n, 4)).astype(np.float32), rng.normal(0, 1, (n, 4)).astype(np.float32)
+    s0, s1 = np.exp(rng.normal(-1, 0.5, (n, 3))).astype(np.float32), np.exp(rng.normal(-1, 0.5, (n, 3))).astype(np.float32)
+    got = densify.kl_div(t(mu0), t(q0), t(s0), t(mu1), t(q1), t(s1)).numpy()
+    want = do.kl_div(mu0, q0, s0, mu1, q1, s1)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-4)
+    assert (want > -1e-9).all()  # a divergence
+    # rotating both Gaussians and the offset by the same rotation changes nothing
+
+    def qmul(a, b):
+        w1, x1, y1, z1 = a
+        w2, x2, y2, z2 = b.T
+        return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], 1)
+    qa = rng.normal(0, 1, 4)
+    qa /= np.linalg.norm(qa)
+    Ra = do.build_rotation(qa[None].astype(np.float32))[0].astype(np.float64)
+    again = do.kl_div((mu0 @ Ra.T).astype(np.float32), qmul(qa, q0.astype(np.float64)).astype(np.float32), s0,
+                      (mu1 @ Ra.T).astype(np.float32), qmul(qa, q1.astype(np.float64)).astype(np.float32), s1)
+    np.testing.assert_allclose(again, want, rtol=1e-4, atol=1e-4)
