@@ -148,7 +148,7 @@ class Scene:
         from mygauhuman_amd.fastpath import RasterSession
         self.name, self.wl = name, WORKLOADS[name]
         wl = self.wl
-        self.P, self.W, self.H, self.deg = wl["P"], wl["W"], wl["H"], wl["deg"]
+        self.P, self.W, self.H, self.deg = int(os.environ.get("GSR_BENCH_P", wl["P"])), wl["W"], wl["H"], wl["deg"]
         self.M = (self.deg + 1) ** 2
         self.g = synthetic.uniform_gaussians(self.P, seed=0, sh_degree=self.deg, log_scale_mean=wl.get("log_scale", math.log(0.01)))
         self.gt, self.mask = synthetic.loss_targets(self.W, self.H, seed=0)

@@ -46,11 +46,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_count_kernel(const GeomState
 // exclusive scan of counts[tiles] -> ranges[t] = (start, end); cursor[t] = start
 // If the instance total exceeds `capacity` (only possible when the host sized the buffer without knowing R) every
 // range is emptied -- nothing is scattered, sorted or blended -- and status[1] is raised for the host to see.
-__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n,
-                                                          const uint32_t *total, uint32_t capacity, uint32_t *status, int CSTRIDE,
-                                                          int check_prefilter) {
-  __shared__ uint32_t wtot[1024 / WAVE];
-  __shared__ uint32_t carry_s;
+// body of the tile scan for ONE workgroup of 1024 threads
+__device__ __forceinline__ void tile_scan_block(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n, const uint32_t *total,
+                                                uint32_t capacity, uint32_t *status, int CSTRIDE, int check_prefilter,
+                                                uint32_t *wtot, uint32_t *carry_s) {
   const uint32_t R = *total;
   if (threadIdx.x == 0 && status) {
     status[0] = R;
@@ -63,7 +62,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *count
     }
     return;
   }
-  if (threadIdx.x == 0) carry_s = 0;
+  if (threadIdx.x == 0) *carry_s = 0;
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
     const int i = base + threadIdx.x;
@@ -74,7 +73,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *count
     __syncthreads();
     uint32_t woff = 0;
     for (int w = 0; w < wave; w++) woff += wtot[w];
-    const uint32_t carry = carry_s;
+    const uint32_t carry = *carry_s;
     const uint32_t start = carry + woff + incl_w - v;
     if (i < n) {
       cursor[i] = start;
@@ -82,9 +81,16 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *count
       ranges[i] = v ? make_uint2(start, start + v) : make_uint2(0u, 0u);
     }
     __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + incl_w;
+    if (threadIdx.x == 1023) *carry_s = carry + woff + incl_w;
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n,
+                                                          const uint32_t *total, uint32_t capacity, uint32_t *status, int CSTRIDE,
+                                                          int check_prefilter) {
+  __shared__ uint32_t wtot[1024 / WAVE];
+  __shared__ uint32_t carry_s;
+  tile_scan_block(counts, cursor, ranges, n, total, capacity, status, CSTRIDE, check_prefilter, wtot, &carry_s);
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
@@ -250,6 +256,8 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
 // A workgroup takes 64 tiles (lanes) x PW waves; wave w owns the rows [w * chunk, (w + 1) * chunk): sum them (independent
 // loads), exchange the wave sums through LDS, then re-walk the rows (L2 hits) and write the running prefixes.
 constexpr int PW = 16;
+// (Letting the last workgroup to finish scan the tile totals as well -- ticket counter + __threadfence -- was tried: 31 us instead
+// of 5 + 6 for the two launches; the device-scope fences write back / invalidate the L2s of all eight XCDs.)
 __global__ __launch_bounds__(PW *WAVE) void bucket_hist_prefix_kernel(uint32_t *table, int n_sb, int tiles, uint32_t *totals) {
   __shared__ uint32_t s_sum[PW][WAVE];
   const int lane = threadIdx.x % WAVE, w = threadIdx.x / WAVE;

@@ -86,45 +86,59 @@ __device__ __forceinline__ float3 cov2d(const float3 mean, float fx, float fy, f
 
 constexpr int SH_M = 16;           // coefficients per Gaussian at SH degree 3
 constexpr int SH_ROW = SH_M * 3;   // floats per Gaussian
-constexpr int SH_LDS_ROW = 52;     // padded LDS row (208 B): 16-byte aligned and conflict-free for ds_read_b128
+constexpr int SH_HALF = SH_ROW / 2;  // floats staged at a time: 8 coefficients
+constexpr int SH_LDS_ROW = 28;     // padded LDS row (112 B = 7 x 16 B, odd: conflict-free ds_read_b128)
+constexpr int SH_CPT = SH_HALF / 4;  // 16-byte chunks per row half = chunks per thread per half
 
-// STAGE_SH: the workgroup's 256 x 192-byte SH block is one contiguous 48 KB slab; it is fetched with fully coalesced
-// 16-byte loads into LDS and each thread then evaluates its own row out of LDS (a thread-per-row global access
-// touches 64 different cache lines per instruction and uses 4 bytes of each).
+// STAGE_SH: the workgroup's 256 x 192-byte SH block is one contiguous 48 KB slab; it is fetched with coalesced 16-byte loads
+// into LDS and each thread then evaluates its own row out of LDS (a thread-per-row global access touches 64 different cache
+// lines per instruction and uses 4 bytes of each).  The slab goes through LDS in two halves of 8 coefficients (the second
+// half waits in registers meanwhile): 28 KB instead of 52 KB per workgroup = 5 resident workgroups per CU instead of 3.  With
+// 3, the 782 workgroups of 200k Gaussians were 14 more than the chip holds (768), and that second round cost 6 of 21 us.
 template <bool STAGE_SH>
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const PreprocessArgs a) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / WAVE];
   __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? PRE_BLOCK * SH_LDS_ROW : 4];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  float4 second[STAGE_SH ? SH_CPT : 1];  // this thread's chunks of the second half (fp16 storage: 3 x 8 halves in [0..2])
   if (STAGE_SH) {
     const int first = blockIdx.x * PRE_BLOCK;
     const int nrows = min(PRE_BLOCK, a.P - first);
     if (a.sh_half) {
       // fp16 storage: 96-byte rows, 16-byte chunks of 8 halves, widened to fp32 on the way into LDS (exact)
       const uint4 *slab = reinterpret_cast<const uint4 *>(reinterpret_cast<const _Float16 *>(a.shs) + (size_t)first * SH_ROW);
-      for (int q = threadIdx.x; q < nrows * (SH_ROW / 8); q += PRE_BLOCK) {
-        const int row = q / (SH_ROW / 8), k8 = q % (SH_ROW / 8);
-        const uint4 v = slab[q];
-        const _Float16 *hv = reinterpret_cast<const _Float16 *>(&v);
-        float *dst = &s_sh[row * SH_LDS_ROW + 8 * k8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) dst[e] = (float)hv[e];
+      for (int j = 0; j < SH_CPT / 2; j++) {
+        const int e = (int)threadIdx.x + j * PRE_BLOCK, row = e / (SH_CPT / 2), c8 = e % (SH_CPT / 2);
+        if (row < nrows) {
+          const uint4 v = slab[row * (SH_ROW / 8) + c8];
+          second[j] = __builtin_bit_cast(float4, slab[row * (SH_ROW / 8) + SH_CPT / 2 + c8]);
+          const _Float16 *hv = reinterpret_cast<const _Float16 *>(&v);
+          float *dst = &s_sh[row * SH_LDS_ROW + 8 * c8];
+#pragma unroll
+          for (int e2 = 0; e2 < 8; e2++) dst[e2] = (float)hv[e2];
+        }
       }
     } else {
       const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * SH_ROW);
-      for (int q = threadIdx.x; q < nrows * (SH_ROW / 4); q += PRE_BLOCK) {
-        const int row = q / (SH_ROW / 4), k4 = q % (SH_ROW / 4);
-        *reinterpret_cast<float4 *>(&s_sh[row * SH_LDS_ROW + 4 * k4]) = slab[q];
+#pragma unroll
+      for (int j = 0; j < SH_CPT; j++) {
+        const int e = (int)threadIdx.x + j * PRE_BLOCK, row = e / SH_CPT, c4 = e % SH_CPT;
+        if (row < nrows) {
+          *reinterpret_cast<float4 *>(&s_sh[row * SH_LDS_ROW + 4 * c4]) = slab[row * (SH_ROW / 4) + c4];
+          second[j] = slab[row * (SH_ROW / 4) + SH_CPT + c4];
+        }
       }
     }
-    __syncthreads();
   }
   uint32_t tiles = 0;
+  int my_radius = 0;
+  SplatRec rec = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t clamp_bits = 0;
+  bool want_sh = false;  // STAGE_SH: this Gaussian's colour comes from the staged halves below
+  float3 p = make_float3(0.f, 0.f, 0.f);
   if (i < a.P) {
-    int my_radius = 0;
-    SplatRec rec = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t clamp_bits = 0;
-    const float3 p = make_float3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
+    p = make_float3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
     const float3 pv = xform4x3(p, a.view);
     if (pv.z <= 0.2f) {  // CR/auxiliary.h:154
       // The reference prints "Point is filtered although prefiltered is set" and traps the whole context here
@@ -160,11 +174,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
         tile_rect(pix, piy, radi, a.grid_x, a.grid_y, x0, y0, x1, y1);
         const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
         if (area != 0) {
-          float3 rgb;
+          float3 rgb = make_float3(0.f, 0.f, 0.f);
           if (a.colors_precomp) {
             rgb = make_float3(a.colors_precomp[3 * (size_t)i], a.colors_precomp[3 * (size_t)i + 1], a.colors_precomp[3 * (size_t)i + 2]);
+          } else if (STAGE_SH) {
+            want_sh = true;
           } else {
-            rgb = sh_to_rgb(a.D, p, a.campos, STAGE_SH ? &s_sh[threadIdx.x * SH_LDS_ROW] : a.shs + (size_t)i * a.M * 3, clamp_bits);
+            rgb = sh_to_rgb(a.D, p, a.campos, a.shs + (size_t)i * a.M * 3, clamp_bits);
           }
           my_radius = radi;
           tiles = area;
@@ -197,6 +213,45 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
         }
       }
     }
+  }
+  if (STAGE_SH) {
+    float3 d0;
+    const ShDir dir = sh_dir(p, a.campos, d0);
+    float res[3] = {0.f, 0.f, 0.f};
+    __syncthreads();  // first half staged
+    if (want_sh) sh_accumulate<0, SH_M / 2>(a.D, dir, &s_sh[threadIdx.x * SH_LDS_ROW], res);
+    __syncthreads();  // everybody is done reading it
+    {
+      const int nrows = min(PRE_BLOCK, a.P - blockIdx.x * PRE_BLOCK);
+      if (a.sh_half) {
+#pragma unroll
+        for (int j = 0; j < SH_CPT / 2; j++) {
+          const int e = (int)threadIdx.x + j * PRE_BLOCK, row = e / (SH_CPT / 2), c8 = e % (SH_CPT / 2);
+          if (row < nrows) {
+            const _Float16 *hv = reinterpret_cast<const _Float16 *>(&second[j]);
+            float *dst = &s_sh[row * SH_LDS_ROW + 8 * c8];
+#pragma unroll
+            for (int e2 = 0; e2 < 8; e2++) dst[e2] = (float)hv[e2];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < SH_CPT; j++) {
+          const int e = (int)threadIdx.x + j * PRE_BLOCK, row = e / SH_CPT, c4 = e % SH_CPT;
+          if (row < nrows) *reinterpret_cast<float4 *>(&s_sh[row * SH_LDS_ROW + 4 * c4]) = second[j];
+        }
+      }
+    }
+    __syncthreads();
+    if (want_sh) {
+      sh_accumulate<SH_M / 2, SH_M>(a.D, dir, &s_sh[threadIdx.x * SH_LDS_ROW], res);
+      const float3 rgb = sh_finish(res, clamp_bits);
+      rec.r = rgb.x;
+      rec.g = rgb.y;
+      rec.b = rgb.z;
+    }
+  }
+  if (i < a.P) {
     a.radii[i] = my_radius;
     a.geom.tiles_touched[i] = tiles;
     a.geom.clamped[i] = (uint8_t)clamp_bits;

@@ -50,8 +50,20 @@ __device__ __forceinline__ void cov3d_backward(const float3 sc, float mod, const
                4 * z * (dMt[1][1] + dMt[0][0]);
 }
 
-// per-Gaussian body; sh_in / dsh_out point at this Gaussian's [M][3] blocks (global memory, or one LDS row for both)
-__device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs &a, int i, const float *sh_in, float *dsh_out) {
+// what the staged kernel needs to run the SH part itself, half a row at a time
+struct DeferredSh {
+  bool live;       // false: culled Gaussian, its SH gradient is zero
+  float3 mean;
+  float dRGB[3];   // clamp-masked colour gradient
+  float dm[3];     // dL_dmean3D without the SH term (not stored yet)
+};
+
+// per-Gaussian body; sh_in / dsh_out point at this Gaussian's [M][3] blocks in global memory.  DEFER_SH: the SH part and the
+// store of dL_dmean3D are left to the caller (out).
+template <bool DEFER_SH>
+__device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs &a, int i, const float *sh_in, float *dsh_out,
+                                                        DeferredSh *out) {
+  if (DEFER_SH) out->live = false;
   if (!(a.radii[i] > 0)) {
     // culled Gaussian: the reference leaves the zero-initialised outputs untouched (CR/backward.cu:156,367);
     // writing the zeros here lets the host hand in uninitialised tensors (no separate fill kernels)
@@ -70,7 +82,7 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
     a.dL_dopacity[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = 0.f;
-    if (a.shs)
+    if (a.shs && !DEFER_SH)
       for (int k = 0; k < a.M * 3; k++) dsh_out[k] = 0.f;
     return;  // (the extra-channel gradients of the whole workgroup are copied cooperatively by the kernel)
   }
@@ -190,13 +202,25 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
   dm[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
   dm[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
 
-  if (a.shs) {
-    sh_backward(a.D, mean, a.campos, sh_in, a.clamped[i], make_float3(g1.z, g1.w, g2.x), dm, dsh_out);
-    for (int k = (a.D + 1) * (a.D + 1) * 3; k < a.M * 3; k++) dsh_out[k] = 0.f;  // inactive bands
+  if (DEFER_SH) {
+    const uint32_t cb = a.clamped[i];
+    out->live = true;
+    out->mean = mean;
+    out->dRGB[0] = (cb & 1u) ? 0.f : g1.z;
+    out->dRGB[1] = (cb & 2u) ? 0.f : g1.w;
+    out->dRGB[2] = (cb & 4u) ? 0.f : g2.x;
+    out->dm[0] = dm[0];
+    out->dm[1] = dm[1];
+    out->dm[2] = dm[2];
+  } else {
+    if (a.shs) {
+      sh_backward(a.D, mean, a.campos, sh_in, a.clamped[i], make_float3(g1.z, g1.w, g2.x), dm, dsh_out);
+      for (int k = (a.D + 1) * (a.D + 1) * 3; k < a.M * 3; k++) dsh_out[k] = 0.f;  // inactive bands
+    }
+    a.dL_dmean3D[3 * (size_t)i + 0] = dm[0];
+    a.dL_dmean3D[3 * (size_t)i + 1] = dm[1];
+    a.dL_dmean3D[3 * (size_t)i + 2] = dm[2];
   }
-  a.dL_dmean3D[3 * (size_t)i + 0] = dm[0];
-  a.dL_dmean3D[3 * (size_t)i + 1] = dm[1];
-  a.dL_dmean3D[3 * (size_t)i + 2] = dm[2];
 
   if (a.scales) {
     float ds[3], dq[4];
@@ -211,58 +235,122 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
   }
 }
 
-constexpr int BSH_M = 16, BSH_ROW = BSH_M * 3, BSH_LDS_ROW = 52;  // see geometry.hip (padded, conflict-free LDS rows)
+constexpr int BSH_M = 16, BSH_ROW = BSH_M * 3;
+constexpr int BSH_HALF = BSH_ROW / 2;   // floats staged at a time (8 coefficients)
+constexpr int BSH_LDS_ROW = 28;         // padded LDS row, see geometry.hip
+constexpr int BSH_CPT = BSH_HALF / 4;   // 16-byte chunks per thread per half
+constexpr int BWD_BLOCK = 128;          // Gaussians per workgroup: small, so that the 1563 workgroups of 200k Gaussians spread evenly (6-7 per CU)
 
-// STAGE_SH: the workgroup's SH block (256 x 192 B, contiguous) comes in through LDS with coalesced 16-byte loads, each
-// thread works on its LDS row in place (coefficients in, gradients out) and the block goes out coalesced.
+// STAGE_SH: the workgroup's SH block (BWD_BLOCK x 192 B, contiguous) goes through LDS in two halves of 8 coefficients with coalesced
+// 16-byte loads (the second half waits in registers); each thread works on its LDS row in place (coefficients in, gradients
+// out) and the half goes out coalesced.  14 KB of LDS per workgroup instead of 52 (see geometry.hip).
 template <bool STAGE_SH>
-__global__ __launch_bounds__(256) void preprocess_backward_kernel(const PreprocessBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? 256 * BSH_LDS_ROW : 4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(BWD_BLOCK) void preprocess_backward_kernel(const PreprocessBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_sh[STAGE_SH ? BWD_BLOCK * BSH_LDS_ROW : 4];
+  const int i = blockIdx.x * BWD_BLOCK + threadIdx.x;
   if (a.CE > 0) {
     // fused multi-feature blend: the colour gradients of the extra channels pass straight through, columns 9.. of the
-    // gradient rows -> dL_dextra[P][CE]; the workgroup's 256 rows are contiguous on both sides, so the copy is cooperative
+    // gradient rows -> dL_dextra[P][CE]; the workgroup's rows are contiguous on both sides, so the copy is cooperative
     // (coalesced stores); rows of culled Gaussians were never touched by an atomic and are still zero
-    const int first = blockIdx.x * 256;
-    const int nrows = min(256, a.P - first);
+    const int first = blockIdx.x * BWD_BLOCK;
+    const int nrows = min(BWD_BLOCK, a.P - first);
     const float *src = a.grad_rows + (size_t)first * a.grow + 9;
     float *dst = a.dL_dextra + (size_t)first * a.CE;
-    for (int e = threadIdx.x; e < nrows * a.CE; e += 256) {
+    for (int e = threadIdx.x; e < nrows * a.CE; e += BWD_BLOCK) {
       const int r = e / a.CE, c = e - r * a.CE;
       dst[e] = src[(size_t)r * a.grow + c];
     }
   }
   if (STAGE_SH) {
-    const int first = blockIdx.x * 256;
-    const int nrows = min(256, a.P - first);
+    const int first = blockIdx.x * BWD_BLOCK;
+    const int nrows = min(BWD_BLOCK, a.P - first);
+    float4 second[BSH_CPT];  // fp16 storage: 3 x 8 halves in [0..2]
     if (a.sh_half) {  // fp16 storage (see geometry.hip); the gradient that leaves below is fp32 either way
       const uint4 *slab = reinterpret_cast<const uint4 *>(reinterpret_cast<const _Float16 *>(a.shs) + (size_t)first * BSH_ROW);
-      for (int q = threadIdx.x; q < nrows * (BSH_ROW / 8); q += 256) {
-        const int row = q / (BSH_ROW / 8), k8 = q % (BSH_ROW / 8);
-        const uint4 v = slab[q];
-        const _Float16 *hv = reinterpret_cast<const _Float16 *>(&v);
-        float *dst = &s_sh[row * BSH_LDS_ROW + 8 * k8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) dst[e] = (float)hv[e];
+      for (int j = 0; j < BSH_CPT / 2; j++) {
+        const int e = (int)threadIdx.x + j * BWD_BLOCK, row = e / (BSH_CPT / 2), c8 = e % (BSH_CPT / 2);
+        if (row < nrows) {
+          const uint4 v = slab[row * (BSH_ROW / 8) + c8];
+          second[j] = __builtin_bit_cast(float4, slab[row * (BSH_ROW / 8) + BSH_CPT / 2 + c8]);
+          const _Float16 *hv = reinterpret_cast<const _Float16 *>(&v);
+          float *dst = &s_sh[row * BSH_LDS_ROW + 8 * c8];
+#pragma unroll
+          for (int e2 = 0; e2 < 8; e2++) dst[e2] = (float)hv[e2];
+        }
       }
     } else {
       const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * BSH_ROW);
-      for (int q = threadIdx.x; q < nrows * (BSH_ROW / 4); q += 256) {
-        const int row = q / (BSH_ROW / 4), k4 = q % (BSH_ROW / 4);
-        *reinterpret_cast<float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * k4]) = slab[q];
+#pragma unroll
+      for (int j = 0; j < BSH_CPT; j++) {
+        const int e = (int)threadIdx.x + j * BWD_BLOCK, row = e / BSH_CPT, c4 = e % BSH_CPT;
+        if (row < nrows) {
+          *reinterpret_cast<float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * c4]) = slab[row * (BSH_ROW / 4) + c4];
+          second[j] = slab[row * (BSH_ROW / 4) + BSH_CPT + c4];
+        }
+      }
+    }
+    DeferredSh d;
+    d.live = false;
+    if (i < a.P) preprocess_backward_one<true>(a, i, nullptr, nullptr, &d);
+    float3 d0 = make_float3(1.f, 0.f, 0.f);
+    ShDir dir = {};
+    float dd[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (d.live) dir = sh_dir(d.mean, a.campos, d0);
+    float *mine = &s_sh[threadIdx.x * BSH_LDS_ROW];
+    float4 *out = reinterpret_cast<float4 *>(a.dL_dsh + (size_t)first * BSH_ROW);
+    __syncthreads();  // first half staged
+    if (d.live) {
+      sh_backward_range<0, BSH_M / 2>(a.D, dir, mine, d.dRGB, dd);
+    } else if (i < a.P) {
+#pragma unroll
+      for (int k = 0; k < BSH_HALF; k++) mine[k] = 0.f;
+    }
+    __syncthreads();
+    // the first half's gradients leave, the second half's coefficients take their place (same thread, same LDS chunk)
+#pragma unroll
+    for (int j = 0; j < BSH_CPT; j++) {
+      const int e = (int)threadIdx.x + j * BWD_BLOCK, row = e / BSH_CPT, c4 = e % BSH_CPT;
+      if (row < nrows) {
+        float4 *cell = reinterpret_cast<float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * c4]);
+        out[row * (BSH_ROW / 4) + c4] = *cell;
+        if (!a.sh_half) *cell = second[j];
+      }
+    }
+    if (a.sh_half) {
+      __syncthreads();  // the fp16 chunks cover the rows differently (8 floats each): wait until every gradient chunk has left
+#pragma unroll
+      for (int j = 0; j < BSH_CPT / 2; j++) {
+        const int e = (int)threadIdx.x + j * BWD_BLOCK, row = e / (BSH_CPT / 2), c8 = e % (BSH_CPT / 2);
+        if (row < nrows) {
+          const _Float16 *hv = reinterpret_cast<const _Float16 *>(&second[j]);
+          float *dst = &s_sh[row * BSH_LDS_ROW + 8 * c8];
+#pragma unroll
+          for (int e2 = 0; e2 < 8; e2++) dst[e2] = (float)hv[e2];
+        }
       }
     }
     __syncthreads();
-    if (i < a.P) preprocess_backward_one(a, i, &s_sh[threadIdx.x * BSH_LDS_ROW], &s_sh[threadIdx.x * BSH_LDS_ROW]);
+    if (d.live) {
+      sh_backward_range<BSH_M / 2, BSH_M>(a.D, dir, mine, d.dRGB, dd);
+      sh_backward_finish(d0, d.dRGB, dd, d.dm);
+      a.dL_dmean3D[3 * (size_t)i + 0] = d.dm[0];
+      a.dL_dmean3D[3 * (size_t)i + 1] = d.dm[1];
+      a.dL_dmean3D[3 * (size_t)i + 2] = d.dm[2];
+    } else if (i < a.P) {
+#pragma unroll
+      for (int k = 0; k < BSH_HALF; k++) mine[k] = 0.f;
+    }
     __syncthreads();
-    float4 *out = reinterpret_cast<float4 *>(a.dL_dsh + (size_t)first * BSH_ROW);
-    for (int q = threadIdx.x; q < nrows * (BSH_ROW / 4); q += 256) {
-      const int row = q / (BSH_ROW / 4), k4 = q % (BSH_ROW / 4);
-      out[q] = *reinterpret_cast<const float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * k4]);
+#pragma unroll
+    for (int j = 0; j < BSH_CPT; j++) {
+      const int e = (int)threadIdx.x + j * BWD_BLOCK, row = e / BSH_CPT, c4 = e % BSH_CPT;
+      if (row < nrows) out[row * (BSH_ROW / 4) + BSH_CPT + c4] = *reinterpret_cast<const float4 *>(&s_sh[row * BSH_LDS_ROW + 4 * c4]);
     }
   } else {
     if (i < a.P)
-      preprocess_backward_one(a, i, a.shs ? a.shs + (size_t)i * a.M * 3 : nullptr, a.shs ? a.dL_dsh + (size_t)i * a.M * 3 : nullptr);
+      preprocess_backward_one<false>(a, i, a.shs ? a.shs + (size_t)i * a.M * 3 : nullptr,
+                                     a.shs ? a.dL_dsh + (size_t)i * a.M * 3 : nullptr, nullptr);
   }
 }
 
@@ -275,9 +363,9 @@ int launch_preprocess_backward(const PreprocessBwdArgs &a, hipStream_t stream) {
     return GSR_EINVAL;
   }
   if (stage)
-    hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3((a.P + BWD_BLOCK - 1) / BWD_BLOCK), dim3(BWD_BLOCK), 0, stream, a);
   else
-    hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3((a.P + BWD_BLOCK - 1) / BWD_BLOCK), dim3(BWD_BLOCK), 0, stream, a);
   return GSR_OK;
 }
 
