@@ -294,16 +294,56 @@ __global__ __launch_bounds__(PW *WAVE) void bucket_hist_prefix_kernel(uint32_t *
 
 // one workgroup per histogram workgroup, flat over its instances [block_prefix[sb * HG], ...): the slot bases of all tiles are
 // staged in LDS (start + this workgroup's table row), the depth comes from the Gaussian's record
-__global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, int n_pre, int tiles, const uint32_t *start,
+// The tile scan (exclusive prefix of the tile totals -> slot bases, ranges) is part of this kernel: every workgroup needs all the
+// bases in LDS anyway, so each one scans the totals itself (<= 8 per thread + one wave scan, a fraction of a microsecond, all
+// workgroups in parallel) and workgroup 0 also writes ranges[] and the status words -- the separate one-workgroup scan launch
+// between the prefix and the scatter kernel (6 us of launch gap and latency) is gone.
+__global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, int n_pre, int tiles, const uint32_t *totals,
                                                                 const uint32_t *table, const uint32_t *rank, const uint32_t *gids,
-                                                                uint64_t *bucket, uint32_t capacity) {
+                                                                uint64_t *bucket, uint32_t capacity, uint2 *ranges, uint32_t *status,
+                                                                int check_prefilter) {
+  constexpr int PER_MAX = HIST_MAX_TILES / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
+  __shared__ uint32_t s_wtot[HB / WAVE];
   const uint32_t R = *g.total;
-  if (R > capacity) return;  // overflow: see bucket_scan_kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0 && status) {
+    status[0] = R;
+    status[1] = (R > capacity ? 1u : 0u) | ((check_prefilter && g.total[1]) ? 2u : 0u);
+  }
+  if (R > capacity) {  // overflow: nothing is binned, every tile is empty (the caller reads the status words and regrows)
+    if (blockIdx.x == 0)
+      for (int t = threadIdx.x; t < tiles; t += HB) ranges[t] = make_uint2(0u, 0u);
+    return;
+  }
   const uint32_t *row = table + (size_t)blockIdx.x * tiles;
-  for (int t = threadIdx.x; t < tiles; t += HB) s_base[t] = start[t] + row[t];
+  const int per = (tiles + HB - 1) / HB, t0 = (int)threadIdx.x * per;
+  uint32_t cnt[PER_MAX], mine[PER_MAX], local = 0;
+#pragma unroll
+  for (int k = 0; k < PER_MAX; k++) {
+    const int t = t0 + k;
+    const bool in = k < per && t < tiles;
+    cnt[k] = in ? totals[t] : 0u;
+    mine[k] = in ? row[t] : 0u;
+    local += cnt[k];
+  }
+  const uint32_t incl_w = wave_incl_scan(local);
+  const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  if (lane == WAVE - 1) s_wtot[wave] = incl_w;
   const int b0 = blockIdx.x * HG, b1 = min(n_pre, b0 + HG);
   const uint32_t i0 = g.block_prefix[b0], i1 = b1 < n_pre ? g.block_prefix[b1] : R;
+  __syncthreads();
+  uint32_t start = incl_w - local;
+  for (int w = 0; w < wave; w++) start += s_wtot[w];
+#pragma unroll
+  for (int k = 0; k < PER_MAX; k++) {
+    const int t = t0 + k;
+    if (k < per && t < tiles) {
+      s_base[t] = start + mine[k];
+      // empty tiles keep (0, 0) like the reference's zero-filled ranges (CR/rasterizer_impl.cu:312)
+      if (blockIdx.x == 0) ranges[t] = cnt[k] ? make_uint2(start, start + cnt[k]) : make_uint2(0u, 0u);
+      start += cnt[k];
+    }
+  }
   __syncthreads();
   for (uint32_t inst = i0 + threadIdx.x; inst < i1; inst += HB) {
     const uint32_t r = rank[inst];
@@ -673,12 +713,14 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     hipLaunchKernelGGL(bucket_hist_prefix_kernel, dim3((unsigned)((tiles + WAVE - 1) / WAVE)), dim3(PW * WAVE), 0, stream, table, n_sb,
                        (int)tiles, b.tile_counts);
     GSR_LAUNCH_CHECK(stream, debug);
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
-                       g.total, cap32, dev_status, 1, check_prefilter ? 1 : 0);
-    GSR_LAUNCH_CHECK(stream, debug);
-    if (!device_sized && capacity == 0) return GSR_OK;
-    hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, pre_blocks(P), (int)tiles, b.tile_cursor, table,
-                       b.vals_a, b.vals_s, b.keys_a, cap32);
+    if (!device_sized && capacity == 0) {  // nothing to bin (R = 0 read by the host): only the empty ranges and the status
+      hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
+                         g.total, cap32, dev_status, 1, check_prefilter ? 1 : 0);
+      GSR_LAUNCH_CHECK(stream, debug);
+      return GSR_OK;
+    }
+    hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, pre_blocks(P), (int)tiles, b.tile_counts, table,
+                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;
