@@ -114,8 +114,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
 //   (tile scan as before: ranges / start)
 //   scatter : flat over the instances of a workgroup, no expansion: slot = start[tile] + table[workgroup][tile] + rank
 // The arrival order inside a tile is as arbitrary as with atomics; the per-tile sort makes the result deterministic.
-constexpr int HG = 4;                  // preprocess blocks per histogram workgroup
+constexpr int HG = 4;                  // preprocess blocks per histogram workgroup (196 workgroups at 200k: one per CU; 3 -> 261 was slower)
 constexpr int HB = HG * PRE_BLOCK;     // Gaussians (= threads) per histogram workgroup
+constexpr int HB_P2 = HB <= 256 ? 256 : HB <= 512 ? 512 : 1024;
 constexpr int HU = 2;                  // owner searches in flight per lane of the histogram kernel
 constexpr int HIST_MAX_TILES = 8192;   // LDS counters: 32 KB (larger tile grids take the atomic path)
 __device__ __forceinline__ int pre_blocks_dev(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
@@ -127,7 +128,7 @@ template <bool TIGHT, bool SCAN>
 __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, const int *radii, int P, int gx, int gy, int tiles,
                                                         uint32_t *table, uint32_t *rank, uint32_t *gids, uint32_t capacity) {
   __shared__ uint32_t s_cnt[HIST_MAX_TILES];
-  __shared__ uint32_t s_incl[HB];
+  __shared__ uint32_t s_incl[HB_P2];  // padded to a power of two with 0xFFFFFFFF for the branch-free search
   __shared__ uint32_t s_rect[HB];  // x0 | y0 << 10 | width << 20
   __shared__ float4 s_geo[TIGHT ? HB : 1];   // x, y, conic a, conic b
   __shared__ float2 s_geo2[TIGHT ? HB : 1];  // conic c, opacity
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
     if (threadIdx.x < WAVE) {
       uint32_t run = (int)threadIdx.x < HB / WAVE ? s_wsum[threadIdx.x] : 0u;
 #pragma unroll
-      for (int d = HB / WAVE / 2; d >= 1; d >>= 1) run += __shfl_xor(run, d, WAVE);
+      for (int d = WAVE / 2; d >= 1; d >>= 1) run += __shfl_xor(run, d, WAVE);  // (HB / WAVE <= 64 partial sums, zeros behind)
       uint32_t off = own;  // inclusive scan over the HG lanes
 #pragma unroll
       for (int d = 1; d < HG; d <<= 1) {
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
     }
   }
   s_incl[threadIdx.x] = incl;
+  if (HB_P2 > HB && (int)threadIdx.x < HB_P2 - HB) s_incl[HB + threadIdx.x] = 0xFFFFFFFFu;
   s_rect[threadIdx.x] = rect;
   __syncthreads();
   const int nvalid = min(HB, P - first);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
       own[u] = 0;
     }
 #pragma unroll
-    for (int step = HB / 2; step >= 1; step >>= 1) {
+    for (int step = HB_P2 / 2; step >= 1; step >>= 1) {
 #pragma unroll
       for (int u = 0; u < HU; u++) {
         const int idx = own[u] + step;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
                                                                 const uint32_t *table, const uint32_t *rank, const uint32_t *gids,
                                                                 uint64_t *bucket, uint32_t capacity, uint2 *ranges, uint32_t *status,
                                                                 int check_prefilter) {
-  constexpr int PER_MAX = HIST_MAX_TILES / HB;
+  constexpr int PER_MAX = (HIST_MAX_TILES + HB - 1) / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
   const uint32_t R = *g.total;
