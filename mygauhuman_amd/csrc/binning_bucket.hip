@@ -17,6 +17,7 @@
 //                (> 8192 entries) are sorted by the same workgroup as LDS-sized runs merged in global memory.
 // The result (point_list, ranges, sorted keys) is bit-identical to the global radix back-end; traffic drops from
 // ~150 B to ~30 B per instance and the kernel count from 20 to 4.
+#include <atomic>
 #include "expand.h"
 #include "gsr_common.h"
 
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
 // ---- atomics-free counting (Options::bucket_hist, default on) ---------------------------------------------------------------
 // The count pass above is bound by the memory side: one scattered 4-byte returning atomic per instance is one 64-byte request
 // each (~25 k requests / us chip-wide: 0.97 M instances = 34 us at C3).  Here no instance touches a global atomic:
-//   hist    : a workgroup owns HG consecutive preprocess blocks, keeps one counter per TILE in LDS, and every instance takes
+//   hist    : a workgroup owns `hbv` <= HB consecutive Gaussians (an even split of P over a multiple of the CU count, see
+//             hist_split), keeps one counter per TILE in LDS, and every instance takes
 //             its rank among the workgroup's instances of that tile with an LDS returning add; per instance it leaves
 //             (tile << 16 | rank) and the Gaussian id in instance order (coalesced), the counters go out as one dense row
 //             table[workgroup][tile]
@@ -114,9 +116,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomSta
 //   (tile scan as before: ranges / start)
 //   scatter : flat over the instances of a workgroup, no expansion: slot = start[tile] + table[workgroup][tile] + rank
 // The arrival order inside a tile is as arbitrary as with atomics; the per-tile sort makes the result deterministic.
-constexpr int HG = 4;                  // preprocess blocks per histogram workgroup (196 workgroups at 200k: one per CU; 3 -> 261 was slower)
-constexpr int HB = HG * PRE_BLOCK;     // Gaussians (= threads) per histogram workgroup
-constexpr int HB_P2 = HB <= 256 ? 256 : HB <= 512 ? 512 : 1024;
+constexpr int HB = 1024;               // threads per histogram workgroup = the most Gaussians it can own
+constexpr int HNB = HB / PRE_BLOCK + 1;  // preprocess blocks a workgroup's Gaussian range can touch
+constexpr int HB_P2 = 1024;
 constexpr int HU = 2;                  // owner searches in flight per lane of the histogram kernel
 constexpr int HIST_MAX_TILES = 8192;   // LDS counters: 32 KB (larger tile grids take the atomic path)
 __device__ __forceinline__ int pre_blocks_dev(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
@@ -126,31 +128,35 @@ __device__ __forceinline__ int pre_blocks_dev(int P) { return (P + PRE_BLOCK - 1
 // writes R -- which saves a single-workgroup launch on the asynchronous path (the blocking path needs R on the host earlier).
 template <bool TIGHT, bool SCAN>
 __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, const int *radii, int P, int gx, int gy, int tiles,
-                                                        uint32_t *table, uint32_t *rank, uint32_t *gids, uint32_t capacity) {
+                                                        uint32_t *table, uint32_t *rank, uint32_t *gids, uint32_t capacity, int hbv,
+                                                        uint32_t *wg_start) {
   __shared__ uint32_t s_cnt[HIST_MAX_TILES];
-  __shared__ uint32_t s_incl[HB_P2];  // padded to a power of two with 0xFFFFFFFF for the branch-free search
+  __shared__ uint32_t s_incl[HB_P2];  // padded with 0xFFFFFFFF for the branch-free search
   __shared__ uint32_t s_rect[HB];  // x0 | y0 << 10 | width << 20
   __shared__ float4 s_geo[TIGHT ? HB : 1];   // x, y, conic a, conic b
   __shared__ float2 s_geo2[TIGHT ? HB : 1];  // conic c, opacity
   __shared__ uint32_t s_wsum[HB / WAVE];
-  __shared__ uint32_t s_boff[HG + 1];        // [0] = instances in front of this workgroup, [1 + k] = offset of its block k
-  const int first = blockIdx.x * HB;
+  __shared__ uint32_t s_boff[HNB + 2];  // [0] = instances in front of block b0, [1 + k] = offset of block b0 + k, [HNB + 1] = see below
+  const int first = blockIdx.x * hbv;   // this workgroup owns the Gaussians [first, first + hbv)
   const int i = first + (int)threadIdx.x;
-  const int b0 = blockIdx.x * HG, n_pre = pre_blocks_dev(P);
+  const bool has = (int)threadIdx.x < hbv && i < P;
+  const int b0 = first / PRE_BLOCK, n_pre = pre_blocks_dev(P);
   for (int t = threadIdx.x; t < tiles; t += HB) s_cnt[t] = 0;
   // this thread's Gaussian: issue the loads before the scan of the block sums so both latencies overlap
   uint32_t incl_local = 0;
   int rad = 0;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-  if (i < P) {
+  if (has) {
     incl_local = g.block_incl[i];
     rad = radii[i];
     r0 = reinterpret_cast<const float4 *>(g.recs + i)[0];
     if (TIGHT) r1 = reinterpret_cast<const float4 *>(g.recs + i)[1];
   }
+  // instances of block b0 that belong to the workgroup in front (the range need not start on a block boundary)
+  if (threadIdx.x == HB - 1) s_boff[HNB + 1] = (first % PRE_BLOCK) ? g.block_incl[first - 1] : 0u;
   if (SCAN) {
-    // own = the sums of this workgroup's HG blocks (lanes 0..HG-1 of wave 0), part = everything in front of the workgroup
-    const uint32_t own = ((int)threadIdx.x < HG && b0 + (int)threadIdx.x < n_pre) ? g.block_sums[b0 + threadIdx.x] : 0u;
+    // own = the sums of the blocks this range touches (lanes 0..HNB-1 of wave 0), part = every block in front of b0
+    const uint32_t own = ((int)threadIdx.x < HNB && b0 + (int)threadIdx.x < n_pre) ? g.block_sums[b0 + threadIdx.x] : 0u;
     uint32_t part = 0;
     for (int b = threadIdx.x; b < b0; b += HB) part += g.block_sums[b];
 #pragma unroll
@@ -161,34 +167,38 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
       uint32_t run = (int)threadIdx.x < HB / WAVE ? s_wsum[threadIdx.x] : 0u;
 #pragma unroll
       for (int d = WAVE / 2; d >= 1; d >>= 1) run += __shfl_xor(run, d, WAVE);  // (HB / WAVE <= 64 partial sums, zeros behind)
-      uint32_t off = own;  // inclusive scan over the HG lanes
+      uint32_t off = own;  // inclusive scan over the HNB lanes
 #pragma unroll
-      for (int d = 1; d < HG; d <<= 1) {
+      for (int d = 1; d < HNB; d <<= 1) {
         const uint32_t up = __shfl_up(off, d, WAVE);
         if ((int)threadIdx.x >= d) off += up;
       }
-      if ((int)threadIdx.x < HG) {
+      if ((int)threadIdx.x < HNB) {
         s_boff[1 + threadIdx.x] = off - own;
-        if (b0 + (int)threadIdx.x < n_pre) g.block_prefix[b0 + threadIdx.x] = run + off - own;
+        // every block prefix is written by the workgroup that owns the block's first Gaussian
+        const int blk = b0 + (int)threadIdx.x, blk_first = blk * PRE_BLOCK;
+        if (blk < n_pre && blk_first >= first && blk_first < first + hbv) g.block_prefix[blk] = run + off - own;
       }
       if (threadIdx.x == 0) s_boff[0] = run;
-      if ((int)threadIdx.x == HG - 1 && blockIdx.x == gridDim.x - 1) g.total[0] = run + off;  // the last blocks: this is R
+      if ((int)threadIdx.x == HNB - 1 && blockIdx.x == gridDim.x - 1) g.total[0] = run + off;  // the last blocks: this is R
     }
     __syncthreads();
   } else {
-    if (threadIdx.x <= HG) {
+    if ((int)threadIdx.x <= HNB) {
       const uint32_t base = g.block_prefix[b0];
       if (threadIdx.x == 0) s_boff[0] = base;
       else s_boff[threadIdx.x] = (b0 + (int)threadIdx.x - 1 < n_pre ? g.block_prefix[b0 + threadIdx.x - 1] : base) - base;
     }
     __syncthreads();
   }
-  const uint32_t sb_prefix = s_boff[0];
+  const uint32_t sb_prefix = s_boff[0] + s_boff[HNB + 1];  // global index of the workgroup's first instance
+  if (threadIdx.x == 0) wg_start[blockIdx.x] = sb_prefix;
   uint32_t incl = 0xFFFFFFFFu, rect = 0;
-  if (i < P) {
-    // inclusive scan of tiles_touched inside this workgroup = block-local scan + the block's offset inside the group
-    incl = incl_local + s_boff[1 + threadIdx.x / PRE_BLOCK];
-    g.point_offsets[i] = sb_prefix + incl;
+  if (has) {
+    // inclusive scan of tiles_touched: block-local scan + the block's offset; relative to the workgroup for the search below
+    const uint32_t global_incl = s_boff[0] + s_boff[1 + (i / PRE_BLOCK - b0)] + incl_local;
+    incl = global_incl - sb_prefix;
+    g.point_offsets[i] = global_incl;
     if (rad > 0) {
       int x0, y0, x1, y1;
       tile_rect(r0.x, r0.y, rad, gx, gy, x0, y0, x1, y1);
@@ -200,10 +210,9 @@ __global__ __launch_bounds__(HB) void bucket_hist_kernel(const GeomState g, cons
     }
   }
   s_incl[threadIdx.x] = incl;
-  if (HB_P2 > HB && (int)threadIdx.x < HB_P2 - HB) s_incl[HB + threadIdx.x] = 0xFFFFFFFFu;
   s_rect[threadIdx.x] = rect;
   __syncthreads();
-  const int nvalid = min(HB, P - first);
+  const int nvalid = min(hbv, P - first);
   const uint32_t total = s_incl[nvalid - 1];
   // owner search: branch-free descent over the inclusive scan (entries past nvalid hold 0xFFFFFFFF), HU instances per lane in
   // flight so the dependent LDS reads of one search hide behind the other's
@@ -294,16 +303,16 @@ __global__ __launch_bounds__(PW *WAVE) void bucket_hist_prefix_kernel(uint32_t *
   }
 }
 
-// one workgroup per histogram workgroup, flat over its instances [block_prefix[sb * HG], ...): the slot bases of all tiles are
+// one workgroup per histogram workgroup, flat over its instances [wg_start[w], wg_start[w + 1]): the slot bases of all tiles are
 // staged in LDS (start + this workgroup's table row), the depth comes from the Gaussian's record
 // The tile scan (exclusive prefix of the tile totals -> slot bases, ranges) is part of this kernel: every workgroup needs all the
 // bases in LDS anyway, so each one scans the totals itself (<= 8 per thread + one wave scan, a fraction of a microsecond, all
 // workgroups in parallel) and workgroup 0 also writes ranges[] and the status words -- the separate one-workgroup scan launch
 // between the prefix and the scatter kernel (6 us of launch gap and latency) is gone.
-__global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, int n_pre, int tiles, const uint32_t *totals,
-                                                                const uint32_t *table, const uint32_t *rank, const uint32_t *gids,
-                                                                uint64_t *bucket, uint32_t capacity, uint2 *ranges, uint32_t *status,
-                                                                int check_prefilter) {
+__global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, const uint32_t *wg_start, int tiles,
+                                                                const uint32_t *totals, const uint32_t *table, const uint32_t *rank,
+                                                                const uint32_t *gids, uint64_t *bucket, uint32_t capacity,
+                                                                uint2 *ranges, uint32_t *status, int check_prefilter) {
   constexpr int PER_MAX = (HIST_MAX_TILES + HB - 1) / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
@@ -331,8 +340,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   const uint32_t incl_w = wave_incl_scan(local);
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   if (lane == WAVE - 1) s_wtot[wave] = incl_w;
-  const int b0 = blockIdx.x * HG, b1 = min(n_pre, b0 + HG);
-  const uint32_t i0 = g.block_prefix[b0], i1 = b1 < n_pre ? g.block_prefix[b1] : R;
+  const uint32_t i0 = wg_start[blockIdx.x], i1 = blockIdx.x + 1 < gridDim.x ? wg_start[blockIdx.x + 1] : R;
   __syncthreads();
   uint32_t start = incl_w - local;
   for (int w = 0; w < wave; w++) start += s_wtot[w];
@@ -667,10 +675,38 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
   }
 }
 
+// The histogram / scatter workgroups split the P Gaussians EVENLY over a multiple of the CU count (at most HB each, at least one
+// preprocess block): 200k Gaussians on 256 CUs = 256 workgroups of 782 instead of 196 of 1024 with 60 CUs idle.
+static int cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+static void hist_split(int P, int &n_sb, int &hbv) {
+  const int cus = cu_count();
+  const int rounds = (int)(((size_t)P + (size_t)cus * HB - 1) / ((size_t)cus * HB));
+  int n = cus * (rounds > 0 ? rounds : 1);
+  const int most = pre_blocks(P) > 0 ? pre_blocks(P) : 1;  // not less than one preprocess block per workgroup
+  if (n > most) n = most;
+  hbv = (P + n - 1) / n;
+  if (hbv < 1) hbv = 1;
+  n_sb = (P + hbv - 1) / hbv;
+  if (n_sb < 1) n_sb = 1;
+}
+
 bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity) {
-  const size_t n_sb = (size_t)(pre_blocks(P) + HG - 1) / HG;
-  // the workgroup x tile table borrows keys_s, which nothing touches before the sort kernels write their final keys into it
-  return opt.bucket_hist && tiles <= (size_t)HIST_MAX_TILES && n_sb * tiles * sizeof(uint32_t) <= capacity * sizeof(uint64_t);
+  int n_sb, hbv;
+  hist_split(P, n_sb, hbv);
+  // the workgroup x tile table (+ one start word per workgroup) borrows keys_s, which nothing touches before the sort kernels
+  // write their final keys into it
+  return opt.bucket_hist && tiles <= (size_t)HIST_MAX_TILES &&
+         ((size_t)n_sb * tiles + (size_t)n_sb) * sizeof(uint32_t) <= capacity * sizeof(uint64_t);
 }
 
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
@@ -687,7 +723,8 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   }
   const uint32_t cap32 = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
   // instance ranks live in the (otherwise unused in this back-end) vals_a array
-  const int n_sb = (pre_blocks(P) + HG - 1) / HG;
+  int n_sb, hbv;
+  hist_split(P, n_sb, hbv);
   const bool hist = bucket_uses_hist(opt, P, tiles, capacity);
   if (scan_fused && !hist) {
     set_error("bucket_binning: the fused block scan needs the histogram path");
@@ -695,21 +732,22 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   }
   if (hist) {
     uint32_t *table = reinterpret_cast<uint32_t *>(b.keys_s);
+    uint32_t *wg_start = table + (size_t)n_sb * tiles;
     const dim3 hg(n_sb), hb(HB);
     if (scan_fused) {
       if (opt.tile_cull)
         hipLaunchKernelGGL((bucket_hist_kernel<true, true>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
-                           b.vals_s, cap32);
+                           b.vals_s, cap32, hbv, wg_start);
       else
         hipLaunchKernelGGL((bucket_hist_kernel<false, true>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
-                           b.vals_s, cap32);
+                           b.vals_s, cap32, hbv, wg_start);
     } else {
       if (opt.tile_cull)
         hipLaunchKernelGGL((bucket_hist_kernel<true, false>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
-                           b.vals_s, cap32);
+                           b.vals_s, cap32, hbv, wg_start);
       else
         hipLaunchKernelGGL((bucket_hist_kernel<false, false>), hg, hb, 0, stream, g, radii, P, grid_x, grid_y, (int)tiles, table, b.vals_a,
-                           b.vals_s, cap32);
+                           b.vals_s, cap32, hbv, wg_start);
     }
     GSR_LAUNCH_CHECK(stream, debug);
     hipLaunchKernelGGL(bucket_hist_prefix_kernel, dim3((unsigned)((tiles + WAVE - 1) / WAVE)), dim3(PW * WAVE), 0, stream, table, n_sb,
@@ -721,7 +759,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
       GSR_LAUNCH_CHECK(stream, debug);
       return GSR_OK;
     }
-    hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, pre_blocks(P), (int)tiles, b.tile_counts, table,
+    hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
                        b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
