@@ -97,6 +97,7 @@ __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *count
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
                                                                   const uint32_t *start, const uint32_t *rank,
                                                                   uint64_t *bucket, uint32_t capacity) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) g.total[2] = 0;  // work-list counter of the sort kernels that follow
   if (*g.total > capacity) return;  // overflow: see bucket_scan_kernel
   expand_block_instances(g, radii, P, gx, gy, false, [&](uint32_t inst, uint32_t gid, uint32_t tile, uint32_t dbits) {
     const uint32_t r = rank[inst];
@@ -317,9 +318,12 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
   const uint32_t R = *g.total;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && status) {
-    status[0] = R;
-    status[1] = (R > capacity ? 1u : 0u) | ((check_prefilter && g.total[1]) ? 2u : 0u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g.total[2] = 0;  // work-list counter of the sort kernels that follow
+    if (status) {
+      status[0] = R;
+      status[1] = (R > capacity ? 1u : 0u) | ((check_prefilter && g.total[1]) ? 2u : 0u);
+    }
   }
   if (R > capacity) {  // overflow: nothing is binned, every tile is empty (the caller reads the status words and regrows)
     if (blockIdx.x == 0)
@@ -540,12 +544,16 @@ __device__ __forceinline__ void wave_sort_tile_runs(const uint64_t *b, int n, ui
 }
 
 __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ranges, const uint64_t *bucket, uint32_t *point_list,
-                                                               uint64_t *keys_sorted) {
+                                                               uint64_t *keys_sorted, uint32_t *big_list, uint32_t *big_count) {
   __shared__ uint64_t s_runs[MERGE_MAX_RUNS * WAVE];
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const uint2 r = ranges[tile];
   const int n = (int)(r.y - r.x);
-  if (n == 0 || n > SORT_WAVE_MAX) return;
+  if (n > SORT_WAVE_MAX) {  // left to bucket_sort_kernel: onto its work list (any order: every tile is sorted by itself)
+    if (lane == 0) big_list[atomicAdd(big_count, 1u)] = tile;
+    return;
+  }
+  if (n == 0) return;
   const uint64_t *b = bucket + r.x;
   if (n <= 64)
     wave_sort_tile<1>(b, n, tile, r.x, point_list, keys_sorted, lane);
@@ -653,24 +661,18 @@ __device__ __forceinline__ void sort_big_tile(uint32_t tile, uint64_t *s_keys, c
   }
 }
 
-// Lists longer than SORT_WAVE_MAX are rare (none at C3), so the workgroups stride over the tiles instead of one launch slot
-// per tile: a grid of a few hundred workgroups skims the ranges (5 us of empty workgroups before) and sorts what it finds.
+// Lists longer than SORT_WAVE_MAX: none at C3, most of the non-empty tiles of a close-up of a body.  The wave kernel leaves
+// their tile ids on a work list and a fixed grid of workgroups strides over that list: nothing but one counter read when the
+// list is empty, and an even share per workgroup wherever the long lists sit on the screen.  (One workgroup per tile: 5 us of
+// empty workgroups at C3; workgroups striding over the TILES: 113 instead of 50 us in the render() frame, because the tiles
+// of a body fall on a quarter of the workgroups.)
 template <int CAP, int LO, bool TAKES_OVERSIZE>
 __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, uint64_t *bucket, uint32_t *point_list,
-                                                         uint64_t *keys_sorted, uint32_t n_tiles) {
+                                                         uint64_t *keys_sorted, const uint32_t *big_list, const uint32_t *big_count) {
   __shared__ uint64_t s_keys[CAP];
-  __shared__ int s_any;
-  if (threadIdx.x == 0) s_any = 0;
-  __syncthreads();
-  // one round of independent loads over this workgroup's tiles: is there anything to do at all?
-  for (uint32_t t = blockIdx.x + threadIdx.x * gridDim.x; t < n_tiles; t += 256u * gridDim.x) {
-    const uint2 r = ranges[t];
-    if ((int)(r.y - r.x) > LO) s_any = 1;
-  }
-  __syncthreads();
-  if (!s_any) return;
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    sort_big_tile<CAP, LO, TAKES_OVERSIZE>(tile, s_keys, ranges, bucket, point_list, keys_sorted);
+  const uint32_t count = *big_count;
+  for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+    sort_big_tile<CAP, LO, TAKES_OVERSIZE>(big_list[k], s_keys, ranges, bucket, point_list, keys_sorted);
     __syncthreads();  // s_keys is reused by the next tile
   }
 }
@@ -780,12 +782,15 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
                        b.tile_cursor, b.vals_a, b.keys_a, cap32);
     GSR_LAUNCH_CHECK(stream, debug);
   }
-  hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, stream, ranges, b.keys_a, b.vals_s, b.keys_s);
+  // work list of the long lists: tile_cursor is free by now (the scatter kernels are its last readers), total[2] was zeroed by them
+  hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, stream, ranges, b.keys_a, b.vals_s, b.keys_s,
+                     b.tile_cursor, g.total + 2);
   GSR_LAUNCH_CHECK(stream, debug);
   // (a separate 16 KB-LDS instantiation for 1025..2048 keys was measured: slower -- the register sorts of the runs, not the
   // LDS occupancy, bound this kernel)
-  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(256), 0,
-                     stream, ranges, b.keys_a, b.vals_s, b.keys_s, (uint32_t)tiles);
+  const unsigned big_grid = 2u * (unsigned)cu_count();  // 64 KB of LDS each: two per CU
+  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)(tiles < big_grid ? tiles : big_grid)), dim3(256),
+                     0, stream, ranges, b.keys_a, b.vals_s, b.keys_s, b.tile_cursor, g.total + 2);
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;
 }
