@@ -384,7 +384,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {wl['desc']}; S-uniform seed 0, FoV 50deg, "
+            "config": {"workload": f"{a.workload}: {wl['desc']}; "
+                                   + (f"P OVERRIDDEN to {P} by GSR_BENCH_P (a profiling experiment, NOT the headline workload); "
+                                      if P != wl["P"] else "") + "S-uniform seed 0, FoV 50deg, "
                                    + ("identity camera" if world == 1 else
                                       f"{world} views/step, 1 view/rank (cameras orbiting the scene centre in 3deg steps), "
                                       + ("REHEARSAL: all ranks on ONE device over gloo with host-staged collectives -- functional "
