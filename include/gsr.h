@@ -354,6 +354,23 @@ int gsr_smpl_pose_backward(const float *poses, const float *correct_Rs, const fl
 int gsr_gemv_rows(int rows, int cols, const float *mat, const float *vec, float *out, gsr_stream_t stream);
 int gsr_gemv_rows_t(int rows, int cols, const float *mat, const float *dout, float *dvec, gsr_stream_t stream);
 
+/* The parameter activations render() applies every frame (the reference's property getters, scene/gaussian_model.py:157-199,
+ * and the occlusion placeholder of gaussian_renderer/__init__.py:141), P rows each, one kernel:
+ *   opacity[1] = sigmoid(opacity_raw)   albedo[3] = sigmoid(albedo_raw)   scaling[3] = exp(scaling_raw)
+ *   rotation[4] = rotation_raw / max(|rotation_raw|, 1e-12)   normal[3] = normal_raw / |normal_raw|   occlusion[3] = opacity x3
+ * (get_roughness reads _albedo as well in the reference, :197-199: callers alias the albedo output for it). */
+int gsr_model_activations_forward(int P, const float *opacity_raw, const float *albedo_raw, const float *scaling_raw,
+                                  const float *rotation_raw, const float *normal_raw, float *opacity, float *albedo,
+                                  float *scaling, float *rotation, float *normal, float *occlusion, gsr_stream_t stream);
+
+/* Backward of gsr_model_activations_forward: opacity / albedo / scaling are the forward's outputs, g_* the gradients of the six
+ * outputs (a null g_* = that output did not reach the loss), d_*_raw are fully written. */
+int gsr_model_activations_backward(int P, const float *rotation_raw, const float *normal_raw, const float *opacity,
+                                   const float *albedo, const float *scaling, const float *g_opacity, const float *g_albedo,
+                                   const float *g_scaling, const float *g_rotation, const float *g_normal,
+                                   const float *g_occlusion, float *d_opacity_raw, float *d_albedo_raw, float *d_scaling_raw,
+                                   float *d_rotation_raw, float *d_normal_raw, gsr_stream_t stream);
+
 /* Per-frame, per-Gaussian attributes render() derives between the LBS deform and the rasterizer
  * (gaussian_renderer/__init__.py:128-198; scene/gaussian_model.py:35-42,186-190; utils/general_utils.py:64-157;
  * utils/sh_utils.py:57-117; transform.py:9-17) -- one kernel instead of the reference's torch op chain.

@@ -23,6 +23,7 @@ SOURCES = [
     ("preprocess_bwd.hip", []),
     ("lbs.hip", []),
     ("attributes.hip", []),
+    ("activations.hip", []),
     ("pose.hip", []),
     ("sh_exchange.hip", []),
     ("rows.hip", []),

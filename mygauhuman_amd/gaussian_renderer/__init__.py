@@ -60,8 +60,11 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
         sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
+    # the parameter activations: one fused kernel when the model offers it (scene_model.HumanGaussianModel.frame_activations),
+    # the reference's property getters otherwise
+    act = pc.frame_activations() if (hasattr(pc, "frame_activations") and not getattr(pipe, "property_activations", False)) else None
     means3D = pc.get_xyz
-    normal = pc.get_normal
+    normal = act.normal if act is not None else pc.get_normal
     correct_Rs = None
     if not pc.motion_offset_flag:
         _, means3D, _, transforms, _, world_normal = _deform(pc, means3D, normal, viewpoint_camera)
@@ -77,9 +80,11 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
 
     means3D = means3D.reshape(-1, 3)
     means2D = screenspace_points
-    opacity = pc.get_opacity
-    albedo = pc.get_albedo
-    roughness = pc.get_roughness
+    opacity = act.opacity if act is not None else pc.get_opacity
+    albedo = act.albedo if act is not None else pc.get_albedo
+    roughness = act.roughness if act is not None else pc.get_roughness
+    scaling = act.scaling if act is not None else pc.get_scaling
+    rotation_n = act.rotation if act is not None else pc.get_rotation
     occlusion = getattr(viewpoint_camera, "occlusion", None)
     if iteration > 30000 and occlusion is not None:
         occlusion = occlusion.detach()
@@ -89,20 +94,20 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
         else:
             _occlusion = occlusion.sum(dim=(1, 2))
     else:
-        _occlusion = opacity.repeat(1, 3)
+        _occlusion = act.occlusion if act is not None else opacity.repeat(1, 3)
 
     # covariance in the posed frame, view-dependent colour and the six feature colour sets (:120-198): one HIP kernel
     # (mygauhuman_amd.attributes)
     sh_python = override_color is None and pipe.convert_SHs_python
     cov3D_precomp, colors_precomp, features = frame_attributes(
-        means3D, transforms.reshape(-1, 3, 3), world_normal.reshape(-1, 3), pc.get_scaling, scaling_modifier, pc._rotation,
-        pc.get_rotation, albedo, roughness, _occlusion, pc.get_features if sh_python else None, pc.active_sh_degree,
+        means3D, transforms.reshape(-1, 3, 3), world_normal.reshape(-1, 3), scaling, scaling_modifier, pc._rotation,
+        rotation_n, albedo, roughness, _occlusion, pc.get_features if sh_python else None, pc.active_sh_degree,
         viewpoint_camera.camera_center, viewpoint_camera.world_view_transform)
 
     scales = rotations = shs = None
     if not pipe.compute_cov3D_python:
         cov3D_precomp = None
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        scales, rotations = scaling, rotation_n
     if override_color is not None:
         colors_precomp = override_color
     elif not sh_python:

@@ -107,6 +107,16 @@ class HumanGaussianModel:
     def get_roughness(self):  # the reference returns the albedo activation here too (scene/gaussian_model.py:197-199)
         return torch.sigmoid(self._albedo)
 
+    def frame_activations(self):
+        """All of the above activations in one kernel (mygauhuman_amd.activations): render() asks for this when the model
+        offers it and reads the property getters otherwise (the reference's own GaussianModel)."""
+        from .activations import frame_activations
+        from types import SimpleNamespace
+        opacity, albedo, scaling, rotation, normal, occlusion = frame_activations(self._opacity, self._albedo, self._scaling,
+                                                                                  self._rotation, self._normal)
+        return SimpleNamespace(opacity=opacity, albedo=albedo, roughness=albedo, scaling=scaling, rotation=rotation, normal=normal,
+                               occlusion=occlusion)
+
     def get_covariance(self, scaling_modifier=1, transform=None):
         return covariance.build_covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation, transform)
 

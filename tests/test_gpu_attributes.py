@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import util
+
 pytestmark = pytest.mark.gpu
 
 
@@ -79,3 +81,41 @@ def test_frame_attributes_null_gradients_and_errors():
         cpu = {k: (v.detach().cpu() if v is not None else None) for k, v in d.items()}
         frame_attributes(cpu["means3D"], cpu["transforms"], cpu["world_normals"], cpu["scales"], 1.0, cpu["rot_cov"], cpu["rot_axis"],
                          cpu["albedo"], cpu["roughness"], cpu["occlusion"], cpu["shs"], 3, cam.cpu(), view.cpu())
+
+
+@pytest.mark.parametrize("P", [1, 777, 20000])
+def test_frame_activations_match_the_property_getters(P):
+    """csrc/activations.hip against the torch ops of the reference's getters (scene/gaussian_model.py:157-199) and
+    render()'s opacity.repeat(1, 3): values and the gradients autograd derives, N(0,1) upstream gradients."""
+    import torch.nn.functional as F
+    from mygauhuman_amd.activations import frame_activations
+    rng = np.random.default_rng(P)
+    mk = lambda *s: torch.from_numpy(rng.normal(0, 1.5, s).astype(np.float32)).cuda()  # noqa: E731
+    raw = [mk(P, 1), mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 3)]
+    ups = [mk(P, 1), mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 3), mk(P, 3)]
+
+    def getters(o, a, s, r, n):
+        op = torch.sigmoid(o)
+        return op, torch.sigmoid(a), torch.exp(s), F.normalize(r), n / n.norm(dim=1, keepdim=True), op.repeat(1, 3)
+
+    res = {}
+    for name, fn in (("hip", frame_activations), ("torch", getters)):
+        leaves = [t.clone().requires_grad_(True) for t in raw]
+        outs = fn(*leaves)
+        sum((o * u).sum() for o, u in zip(outs, ups)).backward()
+        res[name] = ([o.detach().cpu().numpy() for o in outs], [t.grad.cpu().numpy() for t in leaves])
+    for a, b in zip(res["hip"][0], res["torch"][0]):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)
+    for k, (a, b) in enumerate(zip(res["hip"][1], res["torch"][1])):
+        util.assert_close(f"raw gradient {k}", a, b, tol=2e-5, max_bad_frac=0)
+    # outputs that do not reach the loss hand None to the backward
+    leaves = [t.clone().requires_grad_(True) for t in raw]
+    outs = frame_activations(*leaves)
+    (outs[0] * ups[0]).sum().backward()
+    want = [t.clone().requires_grad_(True) for t in raw]
+    (torch.sigmoid(want[0]) * ups[0]).sum().backward()
+    np.testing.assert_allclose(leaves[0].grad.cpu().numpy(), want[0].grad.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    for t in leaves[1:]:
+        assert float(t.grad.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        frame_activations(*[t.cpu() for t in raw])

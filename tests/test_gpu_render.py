@@ -308,3 +308,22 @@ def test_render_step_as_one_graph_equals_eager(oracle):
             assert float((p.grad - ge).abs().max()) / scale < 2e-5, trial
     # gradients of the captured backward live in the graph's pool: read them through the tensors captured at record time
     assert all(torch.isfinite(v).all() for v in out.values() if isinstance(v, torch.Tensor) and v.is_floating_point())
+
+
+def test_render_with_fused_activations_equals_property_getters(oracle):
+    """render() reads the model through ONE activation kernel (HumanGaussianModel.frame_activations) by default;
+    `pipe.property_activations = True` goes through the reference-style property getters: same images, same gradients."""
+    from mygauhuman_amd.gaussian_renderer import render
+    outs, grads = {}, {}
+    for prop in (False, True):
+        s = _human_scene(oracle, seed=5)
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, property_activations=prop)
+        o = render(1, s.cam, s.model, pipe, util.to_dev(np.array([0.1, 0.2, 0.3], np.float32)))
+        keys = ("render", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis", "render_alpha")
+        sum(o[k].mean() * (i + 1) for i, k in enumerate(keys)).backward()
+        outs[prop] = {k: o[k].detach().cpu().numpy() for k in keys + ("render_depth",)}
+        grads[prop] = [p.grad.cpu().numpy() for p in s.model.parameters()]
+    for k in outs[False]:
+        np.testing.assert_allclose(outs[False][k], outs[True][k], atol=3e-5, err_msg=k)
+    for ga, gb in zip(grads[False], grads[True]):
+        util.assert_close("render grads", ga, gb, tol=1e-4, max_bad_frac=2e-4)
