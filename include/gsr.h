@@ -404,6 +404,25 @@ int gsr_frame_attributes_backward(int P, int sh_degree, int M, const float *mean
                                   float *dL_drot_cov, float *dL_drot_axis, float *dL_dalbedo, float *dL_droughness,
                                   float *dL_docclusion, float *dL_dshs, gsr_stream_t stream);
 
+/* The same two operations reading the SH coefficients from the model's TWO parameter tensors in place -- shs = the DC
+ * coefficient [P][1][3], shs_rest = the other 15 [P][15][3] (16-byte aligned), M = 16 -- instead of through the torch.cat of
+ * get_features (scene/gaussian_model.py:167-171; 38 MB copied per frame at 200k Gaussians, and split again in backward); the
+ * backward writes dL_dshs [P][1][3] and dL_dshs_rest [P][15][3].  shs_rest = null: exactly the functions above. */
+int gsr_frame_attributes_forward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                       const float *world_normals, const float *scales, float scale_modifier,
+                                       const float *rot_cov, const float *rot_axis, const float *albedo, const float *roughness,
+                                       const float *occlusion, const float *shs, const float *shs_rest, const float *campos,
+                                       const float *viewmatrix, float *cov3D, float *colors, float *features, gsr_stream_t stream);
+int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                        const float *world_normals, const float *scales, float scale_modifier,
+                                        const float *rot_cov, const float *rot_axis, const float *albedo, const float *roughness,
+                                        const float *occlusion, const float *shs, const float *shs_rest, const float *campos,
+                                        const float *viewmatrix, const float *dL_dcov3D, const float *dL_dcolors,
+                                        const float *dL_dfeatures, float *dL_dmeans3D, float *dL_dtransforms,
+                                        float *dL_dworld_normals, float *dL_dscales, float *dL_drot_cov, float *dL_drot_axis,
+                                        float *dL_dalbedo, float *dL_droughness, float *dL_docclusion, float *dL_dshs,
+                                        float *dL_dshs_rest, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

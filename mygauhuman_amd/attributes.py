@@ -16,7 +16,7 @@ from ._lib import check, lib, ptr
 class _FrameAttributes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, transforms, world_normals, scales, rot_cov, rot_axis, albedo, roughness, occlusion, shs, campos,
-                viewmatrix, scale_modifier, sh_degree):
+                viewmatrix, scale_modifier, sh_degree, shs_rest=None):
         if not means3D.is_cuda:
             raise RuntimeError("frame_attributes: tensors must live on a HIP device (no CPU path)")
         dev, f32 = means3D.device, torch.float32
@@ -24,23 +24,26 @@ class _FrameAttributes(torch.autograd.Function):
         c = lambda t: None if t is None else t.detach().contiguous().float()  # noqa: E731
         ins = [c(means3D), c(transforms).reshape(P, 9), c(world_normals), c(scales), c(rot_cov), c(rot_axis), c(albedo),
                c(roughness), c(occlusion), c(shs), c(campos).reshape(3), c(viewmatrix).reshape(16)]
-        M = 0 if shs is None else int(shs.shape[1])
+        rest = c(shs_rest)
+        M = 0 if shs is None else int(shs.shape[1]) + (0 if rest is None else int(rest.shape[1]))
         cov3D = torch.empty((P, 6), dtype=f32, device=dev)
         colors = torch.empty((P, 3), dtype=f32, device=dev) if shs is not None else None
         features = torch.empty((P, 18), dtype=f32, device=dev)
         with torch.cuda.device(dev):
-            check(lib.gsr_frame_attributes_forward(
+            check(lib.gsr_frame_attributes_forward_split(
                 P, int(sh_degree), M, ptr(ins[0]), ptr(ins[1]), ptr(ins[2]), ptr(ins[3]), float(scale_modifier), ptr(ins[4]),
-                ptr(ins[5]), ptr(ins[6]), ptr(ins[7]), ptr(ins[8]), ptr(ins[9]), ptr(ins[10]), ptr(ins[11]), ptr(cov3D),
+                ptr(ins[5]), ptr(ins[6]), ptr(ins[7]), ptr(ins[8]), ptr(ins[9]), ptr(rest), ptr(ins[10]), ptr(ins[11]), ptr(cov3D),
                 ptr(colors), ptr(features), torch.cuda.current_stream(dev).cuda_stream), "gsr_frame_attributes_forward")
         ctx.has_shs = shs is not None
-        ctx.save_for_backward(*[t for t in ins if t is not None])
+        ctx.has_rest = rest is not None
+        ctx.save_for_backward(*([t for t in ins if t is not None] + ([rest] if rest is not None else [])))
         ctx.meta = (float(scale_modifier), int(sh_degree), M, transforms.shape)
         return cov3D, (colors if colors is not None else torch.empty(0, device=dev)), features
 
     @staticmethod
     def backward(ctx, g_cov, g_colors, g_features):
         saved = list(ctx.saved_tensors)
+        rest = saved.pop() if ctx.has_rest else None
         if not ctx.has_shs:
             saved.insert(9, None)
         means3D, transforms, wn, scales, rot_cov, rot_axis, albedo, roughness, occlusion, shs, campos, view = saved
@@ -52,21 +55,30 @@ class _FrameAttributes(torch.autograd.Function):
         new = lambda *s: torch.empty(s, dtype=f32, device=dev)  # noqa: E731
         d_means, d_T, d_wn, d_scales, d_rc, d_ra = new(P, 3), new(P, 9), new(P, 3), new(P, 3), new(P, 4), new(P, 4)
         d_alb, d_rough, d_occ = new(P, 3), new(P, 3), new(P, 3)
-        d_shs = new(P, M, 3) if ctx.has_shs else None
+        d_shs = new(P, M - (rest.shape[1] if rest is not None else 0), 3) if ctx.has_shs else None
+        d_rest = new(P, rest.shape[1], 3) if rest is not None else None
         with torch.cuda.device(dev):
-            check(lib.gsr_frame_attributes_backward(
+            check(lib.gsr_frame_attributes_backward_split(
                 P, D, M, ptr(means3D), ptr(transforms), ptr(wn), ptr(scales), mod, ptr(rot_cov), ptr(rot_axis), ptr(albedo),
-                ptr(roughness), ptr(occlusion), ptr(shs), ptr(campos), ptr(view), ptr(c(g_cov)), ptr(g_colors),
+                ptr(roughness), ptr(occlusion), ptr(shs), ptr(rest), ptr(campos), ptr(view), ptr(c(g_cov)), ptr(g_colors),
                 ptr(c(g_features)), ptr(d_means), ptr(d_T), ptr(d_wn), ptr(d_scales), ptr(d_rc), ptr(d_ra), ptr(d_alb),
-                ptr(d_rough), ptr(d_occ), ptr(d_shs), torch.cuda.current_stream(dev).cuda_stream),
+                ptr(d_rough), ptr(d_occ), ptr(d_shs), ptr(d_rest), torch.cuda.current_stream(dev).cuda_stream),
                 "gsr_frame_attributes_backward")
-        return (d_means, d_T.view(t_shape), d_wn, d_scales, d_rc, d_ra, d_alb, d_rough, d_occ, d_shs, None, None, None, None)
+        return (d_means, d_T.view(t_shape), d_wn, d_scales, d_rc, d_ra, d_alb, d_rough, d_occ, d_shs, None, None, None, None,
+                d_rest)
 
 
 def frame_attributes(means3D, transforms, world_normals, scales, scale_modifier, rot_cov, rot_axis, albedo, roughness, occlusion,
                      shs, sh_degree, campos, viewmatrix):
     """HIP path.  means3D [P,3], transforms [P,3,3], world_normals [P,3] (un-normalised), scales [P,3] (activated),
-    rot_cov / rot_axis [P,4], albedo / roughness / occlusion [P,3], shs [P,M,3] or None."""
+    rot_cov / rot_axis [P,4], albedo / roughness / occlusion [P,3], shs [P,M,3], None, or the model's two parameter tensors
+    (features_dc [P,1,3], features_rest [P,15,3]) as a tuple: they are then read in place, without the torch.cat of
+    get_features."""
+    rest = None
+    if isinstance(shs, (tuple, list)):
+        shs, rest = shs
+        if shs.shape[1] != 1 or rest.shape[1] != 15:
+            shs, rest = torch.cat((shs, rest), dim=1), None
     cov3D, colors, features = _FrameAttributes.apply(means3D, transforms, world_normals, scales, rot_cov, rot_axis, albedo,
-                                                     roughness, occlusion, shs, campos, viewmatrix, scale_modifier, sh_degree)
+                                                     roughness, occlusion, shs, campos, viewmatrix, scale_modifier, sh_degree, rest)
     return cov3D, (colors if shs is not None else None), features

@@ -22,12 +22,14 @@ struct AttrArgs {
   const float *means, *transforms, *world_normals, *scales;
   float mod;
   const float *rot_cov, *rot_axis, *albedo, *roughness, *occlusion, *shs, *campos, *view;
+  const float *shs_rest;  // non-null: shs holds only the DC coefficient [P][1][3], this the other 15 [P][15][3] (the model's two
+                          // parameter tensors, read in place instead of through torch.cat)
   // forward outputs
   float *cov3D, *colors, *features;
   // backward inputs / outputs
   const float *g_cov3D, *g_colors, *g_features;
   float *d_means, *d_transforms, *d_world_normals, *d_scales, *d_rot_cov, *d_rot_axis, *d_albedo, *d_roughness, *d_occlusion,
-      *d_shs;
+      *d_shs, *d_shs_rest;
 };
 
 constexpr int ATTR_BLOCK = 256;
@@ -358,10 +360,30 @@ __global__ __launch_bounds__(ATTR_BLOCK) void attributes_kernel(const AttrArgs a
   if (STAGE) {
     const int first = blockIdx.x * ATTR_BLOCK;
     const int nrows = min(ATTR_BLOCK, a.P - first);
-    const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * ASH_ROW);
-    for (int q = threadIdx.x; q < nrows * (ASH_ROW / 4); q += ATTR_BLOCK) {
-      const int row = q / (ASH_ROW / 4), k4 = q % (ASH_ROW / 4);
-      *reinterpret_cast<float4 *>(&s_sh[row * ASH_LDS_ROW + 4 * k4]) = slab[q];
+    constexpr int REST = ASH_ROW - 3;  // floats of the 15 higher coefficients
+    if (a.shs_rest) {
+      // two source arrays: rows of 3 floats and rows of 45 floats, each block contiguous; 16-byte loads where the block allows
+      const float *dc = a.shs + (size_t)first * 3;
+      for (int e = threadIdx.x; e < nrows * 3; e += ATTR_BLOCK) s_sh[(e / 3) * ASH_LDS_ROW + e % 3] = dc[e];
+      const float *rest = a.shs_rest + (size_t)first * REST;
+      const int n4 = nrows * REST / 4;
+      const float4 *rest4 = reinterpret_cast<const float4 *>(rest);
+      for (int q = threadIdx.x; q < n4; q += ATTR_BLOCK) {
+        const float4 v = rest4[q];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int e = 4 * q + j;
+          s_sh[(e / REST) * ASH_LDS_ROW + 3 + e % REST] = vv[j];
+        }
+      }
+      for (int e = 4 * n4 + (int)threadIdx.x; e < nrows * REST; e += ATTR_BLOCK) s_sh[(e / REST) * ASH_LDS_ROW + 3 + e % REST] = rest[e];
+    } else {
+      const float4 *slab = reinterpret_cast<const float4 *>(a.shs + (size_t)first * ASH_ROW);
+      for (int q = threadIdx.x; q < nrows * (ASH_ROW / 4); q += ATTR_BLOCK) {
+        const int row = q / (ASH_ROW / 4), k4 = q % (ASH_ROW / 4);
+        *reinterpret_cast<float4 *>(&s_sh[row * ASH_LDS_ROW + 4 * k4]) = slab[q];
+      }
     }
     __syncthreads();
     float *row = &s_sh[threadIdx.x * ASH_LDS_ROW];
@@ -373,10 +395,28 @@ __global__ __launch_bounds__(ATTR_BLOCK) void attributes_kernel(const AttrArgs a
     }
     if (BWD) {
       __syncthreads();
-      float4 *out = reinterpret_cast<float4 *>(a.d_shs + (size_t)first * ASH_ROW);
-      for (int q = threadIdx.x; q < nrows * (ASH_ROW / 4); q += ATTR_BLOCK) {
-        const int r = q / (ASH_ROW / 4), k4 = q % (ASH_ROW / 4);
-        out[q] = *reinterpret_cast<const float4 *>(&s_sh[r * ASH_LDS_ROW + 4 * k4]);
+      if (a.shs_rest) {
+        float *dc = a.d_shs + (size_t)first * 3;
+        for (int e = threadIdx.x; e < nrows * 3; e += ATTR_BLOCK) dc[e] = s_sh[(e / 3) * ASH_LDS_ROW + e % 3];
+        float *rest = a.d_shs_rest + (size_t)first * REST;
+        const int n4 = nrows * REST / 4;
+        float4 *rest4 = reinterpret_cast<float4 *>(rest);
+        for (int q = threadIdx.x; q < n4; q += ATTR_BLOCK) {
+          float vv[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int e = 4 * q + j;
+            vv[j] = s_sh[(e / REST) * ASH_LDS_ROW + 3 + e % REST];
+          }
+          rest4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+        for (int e = 4 * n4 + (int)threadIdx.x; e < nrows * REST; e += ATTR_BLOCK) rest[e] = s_sh[(e / REST) * ASH_LDS_ROW + 3 + e % REST];
+      } else {
+        float4 *out = reinterpret_cast<float4 *>(a.d_shs + (size_t)first * ASH_ROW);
+        for (int q = threadIdx.x; q < nrows * (ASH_ROW / 4); q += ATTR_BLOCK) {
+          const int r = q / (ASH_ROW / 4), k4 = q % (ASH_ROW / 4);
+          out[q] = *reinterpret_cast<const float4 *>(&s_sh[r * ASH_LDS_ROW + 4 * k4]);
+        }
       }
     }
   } else if (i < a.P) {
@@ -411,12 +451,39 @@ static int check_common(const char *who, int P, int D, int M, const float *means
 
 extern "C" {
 
+static int split_ok(const char *who, int M, const void *dc, const void *rest, const void *d_dc, const void *d_rest, bool bwd) {
+  if (!rest) return GSR_OK;
+  if (!dc || M != gsr::ASH_M || reinterpret_cast<size_t>(rest) % 16 != 0 ||
+      (bwd && (!d_dc || !d_rest || reinterpret_cast<size_t>(d_rest) % 16 != 0))) {
+    gsr::set_error("%s: split SH arrays need M = 16, the DC array and 16-byte aligned [P][15][3] arrays", who);
+    return GSR_EINVAL;
+  }
+  return GSR_OK;
+}
+
+int gsr_frame_attributes_forward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                       const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
+                                       const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
+                                       const float *shs, const float *shs_rest, const float *campos, const float *viewmatrix,
+                                       float *cov3D, float *colors, float *features, gsr_stream_t stream_);
+
 int gsr_frame_attributes_forward(int P, int sh_degree, int M, const float *means3D, const float *transforms,
                                  const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
                                  const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
                                  const float *shs, const float *campos, const float *viewmatrix, float *cov3D, float *colors,
                                  float *features, gsr_stream_t stream_) {
+  return gsr_frame_attributes_forward_split(P, sh_degree, M, means3D, transforms, world_normals, scales, scale_modifier, rot_cov,
+                                            rot_axis, albedo, roughness, occlusion, shs, nullptr, campos, viewmatrix, cov3D, colors,
+                                            features, stream_);
+}
+
+int gsr_frame_attributes_forward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                       const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
+                                       const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
+                                       const float *shs, const float *shs_rest, const float *campos, const float *viewmatrix,
+                                       float *cov3D, float *colors, float *features, gsr_stream_t stream_) {
   using namespace gsr;
+  if (split_ok("gsr_frame_attributes_forward_split", M, shs, shs_rest, nullptr, nullptr, false) != GSR_OK) return GSR_EINVAL;
   int rc = check_common("gsr_frame_attributes_forward", P, sh_degree, M, means3D, transforms, world_normals, scales, rot_cov,
                         rot_axis, albedo, roughness, occlusion, shs, campos, viewmatrix);
   if (rc != GSR_OK) return rc;
@@ -430,9 +497,9 @@ int gsr_frame_attributes_forward(int P, int sh_degree, int M, const float *means
   a.P = P, a.D = sh_degree, a.M = M;
   a.means = means3D, a.transforms = transforms, a.world_normals = world_normals, a.scales = scales, a.mod = scale_modifier;
   a.rot_cov = rot_cov, a.rot_axis = rot_axis, a.albedo = albedo, a.roughness = roughness, a.occlusion = occlusion;
-  a.shs = shs, a.campos = campos, a.view = viewmatrix;
+  a.shs = shs, a.shs_rest = shs_rest, a.campos = campos, a.view = viewmatrix;
   a.cov3D = cov3D, a.colors = colors, a.features = features;
-  const bool stage = shs && M == ASH_M && reinterpret_cast<size_t>(shs) % 16 == 0;
+  const bool stage = shs && M == ASH_M && (shs_rest || reinterpret_cast<size_t>(shs) % 16 == 0);
   const dim3 grid((P + ATTR_BLOCK - 1) / ATTR_BLOCK), block(ATTR_BLOCK);
   if (stage)
     hipLaunchKernelGGL((attributes_kernel<true, false>), grid, block, 0, stream, a);
@@ -442,6 +509,15 @@ int gsr_frame_attributes_forward(int P, int sh_degree, int M, const float *means
   return GSR_OK;
 }
 
+int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                        const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
+                                        const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
+                                        const float *shs, const float *shs_rest, const float *campos, const float *viewmatrix,
+                                        const float *dL_dcov3D, const float *dL_dcolors, const float *dL_dfeatures,
+                                        float *dL_dmeans3D, float *dL_dtransforms, float *dL_dworld_normals, float *dL_dscales,
+                                        float *dL_drot_cov, float *dL_drot_axis, float *dL_dalbedo, float *dL_droughness,
+                                        float *dL_docclusion, float *dL_dshs, float *dL_dshs_rest, gsr_stream_t stream_);
+
 int gsr_frame_attributes_backward(int P, int sh_degree, int M, const float *means3D, const float *transforms,
                                   const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
                                   const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
@@ -450,7 +526,23 @@ int gsr_frame_attributes_backward(int P, int sh_degree, int M, const float *mean
                                   float *dL_dworld_normals, float *dL_dscales, float *dL_drot_cov, float *dL_drot_axis,
                                   float *dL_dalbedo, float *dL_droughness, float *dL_docclusion, float *dL_dshs,
                                   gsr_stream_t stream_) {
+  return gsr_frame_attributes_backward_split(P, sh_degree, M, means3D, transforms, world_normals, scales, scale_modifier, rot_cov,
+                                             rot_axis, albedo, roughness, occlusion, shs, nullptr, campos, viewmatrix, dL_dcov3D,
+                                             dL_dcolors, dL_dfeatures, dL_dmeans3D, dL_dtransforms, dL_dworld_normals, dL_dscales,
+                                             dL_drot_cov, dL_drot_axis, dL_dalbedo, dL_droughness, dL_docclusion, dL_dshs, nullptr,
+                                             stream_);
+}
+
+int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                        const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
+                                        const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
+                                        const float *shs, const float *shs_rest, const float *campos, const float *viewmatrix,
+                                        const float *dL_dcov3D, const float *dL_dcolors, const float *dL_dfeatures,
+                                        float *dL_dmeans3D, float *dL_dtransforms, float *dL_dworld_normals, float *dL_dscales,
+                                        float *dL_drot_cov, float *dL_drot_axis, float *dL_dalbedo, float *dL_droughness,
+                                        float *dL_docclusion, float *dL_dshs, float *dL_dshs_rest, gsr_stream_t stream_) {
   using namespace gsr;
+  if (split_ok("gsr_frame_attributes_backward_split", M, shs, shs_rest, dL_dshs, dL_dshs_rest, true) != GSR_OK) return GSR_EINVAL;
   int rc = check_common("gsr_frame_attributes_backward", P, sh_degree, M, means3D, transforms, world_normals, scales, rot_cov,
                         rot_axis, albedo, roughness, occlusion, shs, campos, viewmatrix);
   if (rc != GSR_OK) return rc;
@@ -465,12 +557,13 @@ int gsr_frame_attributes_backward(int P, int sh_degree, int M, const float *mean
   a.P = P, a.D = sh_degree, a.M = M;
   a.means = means3D, a.transforms = transforms, a.world_normals = world_normals, a.scales = scales, a.mod = scale_modifier;
   a.rot_cov = rot_cov, a.rot_axis = rot_axis, a.albedo = albedo, a.roughness = roughness, a.occlusion = occlusion;
-  a.shs = shs, a.campos = campos, a.view = viewmatrix;
+  a.shs = shs, a.shs_rest = shs_rest, a.campos = campos, a.view = viewmatrix;
   a.g_cov3D = dL_dcov3D, a.g_colors = dL_dcolors, a.g_features = dL_dfeatures;
   a.d_means = dL_dmeans3D, a.d_transforms = dL_dtransforms, a.d_world_normals = dL_dworld_normals, a.d_scales = dL_dscales;
   a.d_rot_cov = dL_drot_cov, a.d_rot_axis = dL_drot_axis, a.d_albedo = dL_dalbedo, a.d_roughness = dL_droughness;
-  a.d_occlusion = dL_docclusion, a.d_shs = dL_dshs;
-  const bool stage = shs && M == ASH_M && reinterpret_cast<size_t>(shs) % 16 == 0 && reinterpret_cast<size_t>(dL_dshs) % 16 == 0;
+  a.d_occlusion = dL_docclusion, a.d_shs = dL_dshs, a.d_shs_rest = dL_dshs_rest;
+  const bool stage = shs && M == ASH_M &&
+                     (shs_rest || (reinterpret_cast<size_t>(shs) % 16 == 0 && reinterpret_cast<size_t>(dL_dshs) % 16 == 0));
   const dim3 grid((P + ATTR_BLOCK - 1) / ATTR_BLOCK), block(ATTR_BLOCK);
   if (stage)
     hipLaunchKernelGGL((attributes_kernel<true, true>), grid, block, 0, stream, a);

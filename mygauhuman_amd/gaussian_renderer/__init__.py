@@ -41,6 +41,16 @@ def _deform(pc, means3D, normal, cam, lbs_weights=None, correct_Rs=None, return_
     raise RuntimeError("render(): pc.SMPL_NEUTRAL (device tensors incl. kintree_table) is required for the LBS deform")
 
 
+def _features_of(pc, pipe):
+    """The SH coefficients for the attribute kernel: the model's two parameter tensors as they are (no torch.cat) when it has
+    them in the reference's layout, get_features otherwise."""
+    dc, rest = getattr(pc, "_features_dc", None), getattr(pc, "_features_rest", None)
+    if (dc is not None and rest is not None and not getattr(pipe, "property_activations", False) and dc.dim() == 3
+            and rest.dim() == 3 and dc.shape[1] == 1 and rest.shape[1] == 15 and dc.is_contiguous() and rest.is_contiguous()):
+        return (dc, rest)
+    return pc.get_features
+
+
 def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None,
            return_smpl_rot=False, transforms=None, translation=None, envmap=None):
     """Render the scene. Background tensor (bg_color) must be on the GPU."""
@@ -101,7 +111,7 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
     sh_python = override_color is None and pipe.convert_SHs_python
     cov3D_precomp, colors_precomp, features = frame_attributes(
         means3D, transforms.reshape(-1, 3, 3), world_normal.reshape(-1, 3), scaling, scaling_modifier, pc._rotation,
-        rotation_n, albedo, roughness, _occlusion, pc.get_features if sh_python else None, pc.active_sh_degree,
+        rotation_n, albedo, roughness, _occlusion, _features_of(pc, pipe) if sh_python else None, pc.active_sh_degree,
         viewpoint_camera.camera_center, viewpoint_camera.world_view_transform)
 
     scales = rotations = shs = None

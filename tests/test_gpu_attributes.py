@@ -119,3 +119,27 @@ def test_frame_activations_match_the_property_getters(P):
         assert float(t.grad.abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         frame_activations(*[t.cpu() for t in raw])
+
+
+@pytest.mark.parametrize("P,deg", [(1000, 3), (777, 2), (1, 3), (300, 0)])
+def test_frame_attributes_read_the_two_sh_tensors_in_place(P, deg):
+    """shs = (features_dc [P,1,3], features_rest [P,15,3]): same bits as the concatenated [P,16,3] array, gradients land in
+    the two tensors directly."""
+    from mygauhuman_amd.attributes import frame_attributes
+    dev = torch.device("cuda:0")
+    d, cam, view = _inputs(P, 16, 11 + P, dev)
+    g = torch.Generator(device="cpu").manual_seed(P)
+    w = [torch.randn((P, 6), generator=g).to(dev), torch.randn((P, 3), generator=g).to(dev), torch.randn((P, 18), generator=g).to(dev)]
+    (cov_a, col_a, feat_a), ga = _run(frame_attributes, d, cam, view, 1.0, deg, w)
+    dc = d["shs"].detach()[:, :1].clone().requires_grad_(True)
+    rest = d["shs"].detach()[:, 1:].clone().requires_grad_(True)
+    d2 = dict(d, shs=(dc, rest))
+    for v in d.values():
+        v.grad = None
+    cov, col, feat = frame_attributes(d2["means3D"], d2["transforms"], d2["world_normals"], d2["scales"], 1.0, d2["rot_cov"],
+                                      d2["rot_axis"], d2["albedo"], d2["roughness"], d2["occlusion"], d2["shs"], deg, cam, view)
+    ((cov * w[0]).sum() + (col * w[1]).sum() + (feat * w[2]).sum()).backward()
+    assert torch.equal(cov, cov_a) and torch.equal(col, col_a) and torch.equal(feat, feat_a)
+    assert torch.equal(dc.grad, ga["shs"][:, :1]) and torch.equal(rest.grad, ga["shs"][:, 1:])
+    for k in ("means3D", "transforms", "scales", "rot_cov", "albedo"):
+        assert torch.equal(d[k].grad, ga[k]), k
