@@ -303,8 +303,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dopacity = _get("opacity", (P, 1), new)
     dL_dcov3D = _get("cov3D", (P, 6), new)
     dL_dsh = _get("sh", (P, M, 3), new)
-    dL_dscales = _get("scales", (P, 3), new if has_sr else torch.zeros)
-    dL_drotations = _get("rotations", (P, 4), new if has_sr else torch.zeros)
+    # without scales / rotations the reference still returns zero tensors for them (DGR/rasterize_points.cu:159-167); the
+    # autograd wrappers of this package ask for None instead (out["lean"]): nobody reads those two fills
+    lean = bool(out.get("lean")) and not has_sr
+    dL_dscales = None if lean else _get("scales", (P, 3), new if has_sr else torch.zeros)
+    dL_drotations = None if lean else _get("rotations", (P, 4), new if has_sr else torch.zeros)
     dL_dextra = None
     if extra is not None:
         extra = _f32c(extra, "extra")
@@ -329,7 +332,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 binningBuffer.data_ptr(), imageBuffer.data_ptr(), ptr(dL_dout_color), ptr(dL_dout_depth),
                 ptr(dL_dout_alpha), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
-                dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
+                dL_dsh.data_ptr() if M else None, None if dL_dscales is None else dL_dscales.data_ptr(),
+                None if dL_drotations is None else dL_drotations.data_ptr(), int(bool(debug)),
                 ptr(extra), 0 if extra is None else _lib.N_EXTRA, None if extra is None else extra_ptrs,
                 None if dL_dextra is None else dL_dextra.data_ptr(), sh_dtype, _stream(dev))
         check(rc, "gsr_rasterize_backward")

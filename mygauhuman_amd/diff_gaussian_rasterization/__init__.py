@@ -89,6 +89,20 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
+_ZERO_IMAGES = {}
+
+
+def _zero_image(planes, H, W, device):
+    """A zero gradient image nobody writes to (the backward kernels only read their image gradients)."""
+    key = (planes, H, W, device)
+    z = _ZERO_IMAGES.get(key)
+    if z is None:
+        z = torch.zeros((planes, H, W), dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():  # memory of a graph's private pool must not outlive the graph
+            _ZERO_IMAGES[key] = z   # (kept for good: a captured graph may hold its address)
+    return z
+
+
 class _RasterizeGaussiansMulti(torch.autograd.Function):
     """Extension: ONE preprocess + binning + blend for the main colour and 18 extra feature
     channels instead of seven rasterizer calls with identical geometry (gaussian_renderer/__init__.py:203-272)."""
@@ -125,14 +139,16 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha,
          extra) = ctx.saved_tensors
         H, W = alpha.shape[-2], alpha.shape[-1]
-        grad_out_color = torch.zeros((3, H, W), dtype=torch.float32, device=alpha.device) if grad_out_color is None else grad_out_color
-        grad_depth = torch.zeros_like(alpha) if grad_depth is None else grad_depth
-        grad_alpha = torch.zeros_like(alpha) if grad_alpha is None else grad_alpha
+        # images the loss never touched: one shared read-only zero image per (size, device) instead of a fill per backward
+        grad_out_color = _zero_image(3, H, W, alpha.device) if grad_out_color is None else grad_out_color
+        grad_depth = _zero_image(1, H, W, alpha.device) if grad_depth is None else grad_depth
+        grad_alpha = _zero_image(1, H, W, alpha.device) if grad_alpha is None else grad_alpha
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_extra_in) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
-            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, extra=extra, dL_dout_extra=list(grad_feats))
+            geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, out={"lean": True}, extra=extra,
+            dL_dout_extra=list(grad_feats))
         if ctx.watch is not None:
             # the whole backward is queued; wait for the FORWARD's overflow flag only (the GPU stays busy with the backward)
             # so that an overflow raises before the optimizer consumes these gradients
