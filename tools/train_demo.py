@@ -48,7 +48,7 @@ def main(P=200_000, V=6890, W=1024, H=1024, iters=120):
         densify.training_setup(model, dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=0.05, scaling=5e-3, rotation=1e-3,
                                           normal=1e-3, albedo=0.05, roughness=0.05))
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep,
-                                     sync_free_raster=sync_free)
+                                     sync_free_raster=sync_free, property_activations=sep)  # reference structure: property getters
         # the "reference structure" variant also runs the torch op chain for the per-frame attributes
         import mygauhuman_amd.gaussian_renderer as gr
         from mygauhuman_amd.attributes import frame_attributes
