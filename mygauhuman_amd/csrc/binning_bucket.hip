@@ -9,12 +9,13 @@
 //   2. scan    : exclusive scan of the tile counters -> ranges[tile] directly   (replaces identifyTileRanges)
 //   3. scatter : instance -> bucket[start[tile] + rank] = 64-bit sort key (depth bits << 32 | Gaussian id); no
 //                atomics, arrival order is arbitrary
-//   4. sort    : one WAVE per tile bitonic-sorts lists of up to 1024 keys entirely in registers (lane shuffles, no LDS,
-//                no barriers); longer lists get one workgroup and an LDS bitonic sort.  Both write the point list
+//   4. sort    : one WAVE per tile sorts lists of up to 512 keys (64-key runs in registers + rank merge through 4 KB of
+//                LDS, no barriers); longer lists go onto a work list and get one workgroup each: every wave sorts a
+//                quarter in registers, the last merge levels run through LDS.  Both write the point list
 //                (+ the sorted reference keys).  Keys are unique because they contain the Gaussian id, and ordering by
 //                (depth bits, Gaussian id) is exactly what a STABLE sort by (tile, depth bits) gives within a tile,
 //                since the reference emits instances in Gaussian-index order.  Tiles whose list does not fit LDS
-//                (> 8192 entries) are sorted by the same workgroup as LDS-sized runs merged in global memory.
+//                (> 4096 entries) are sorted by the same workgroup as LDS-sized runs merged in global memory.
 // The result (point_list, ranges, sorted keys) is bit-identical to the global radix back-end; traffic drops from
 // ~150 B to ~30 B per instance and the kernel count from 20 to 4.
 #include <atomic>
@@ -23,7 +24,7 @@
 
 namespace gsr {
 
-constexpr int SORT_BIG = 8192;  // LDS capacity (keys) of the workgroup sort used for lists > 1024
+constexpr int SORT_BIG = 4096;  // LDS capacity (keys) of the workgroup sort used for lists > 512; longer lists: chunks + global merge
 
 // One returning atomic per instance: the value it returns is the instance's arrival rank inside its tile, kept in
 // rank[instance] so that the scatter pass needs no second round of atomics.  Counter t lives at counts[t * CSTRIDE]:
@@ -463,7 +464,8 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t *b, int n, uint32_
   }
 }
 
-constexpr int SORT_WAVE_MAX = 1024;  // longest list handled by the register sort (16 keys per lane)
+constexpr int SORT_WAVE_MAX = 512;   // longest list one wave sorts by itself (8 runs of 64 + rank merge); longer ones: bucket_sort_kernel
+constexpr int SORT_RUN_MAX = 1024;   // longest run one wave sorts in registers inside bucket_sort_kernel (16 keys per lane)
 
 // ---- sort by runs + rank merge (lists of 65 .. 512 keys) ---------------------------------------------------------------
 // A full bitonic network over NREG x 64 keys costs log^2 stages over every register and needs a power-of-two size: a tile with
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ran
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const uint2 r = ranges[tile];
   const int n = (int)(r.y - r.x);
-  if (n > SORT_WAVE_MAX) {  // left to bucket_sort_kernel: onto its work list (any order: every tile is sorted by itself)
+  if (n > SORT_WAVE_MAX) {  // left to bucket_sort_kernel: onto its work lists (any order: every tile is sorted by itself)
     if (lane == 0) big_list[atomicAdd(big_count, 1u)] = tile;
     return;
   }
@@ -567,14 +569,13 @@ __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ran
     wave_sort_tile_runs<5>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
   else if (n <= 384)
     wave_sort_tile_runs<6>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
-  else if (n <= 512)
-    wave_sort_tile_runs<8>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
   else
-    wave_sort_tile<16>(b, n, tile, r.x, point_list, keys_sorted, lane);
+    wave_sort_tile_runs<8>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
 }
 
-// CAP = LDS capacity in keys; the instantiation handles tiles with LO < n <= CAP (the big one also n > CAP).  Two
-// launches (1024 / 8192 keys) keep the common short lists at 8 KB of LDS per workgroup = full occupancy.
+// CAP = LDS capacity in keys; handles tiles with LO < n <= CAP in LDS, n > CAP (TAKES_OVERSIZE) as CAP-sized chunks merged in
+// global memory.  Measured in the render() frame (most tiles of the body hold 513..2048 keys): CAP 8192 (64 KB, two workgroups
+// per CU) 65 us; 2048 + a second launch for the longer lists 41 + 5 us; 4096 (32 KB) 40 us in one launch.
 template <int CAP, int LO, bool TAKES_OVERSIZE>
 __device__ __forceinline__ void sort_big_tile(uint32_t tile, uint64_t *s_keys, const uint2 *ranges, uint64_t *bucket,
                                               uint32_t *point_list, uint64_t *keys_sorted) {
@@ -588,22 +589,42 @@ __device__ __forceinline__ void sort_big_tile(uint32_t tile, uint64_t *s_keys, c
     while (np < n) np <<= 1;
     for (int i = threadIdx.x; i < np; i += blockDim.x) s_keys[i] = i < n ? b[i] : ~0ull;
     __syncthreads();
-    if (np >= 2 * SORT_WAVE_MAX) {
-      // runs of 1024 keys are sorted in REGISTERS by one wave each (no barriers; odd runs descending = ascending sort of the
-      // complemented keys), then only the merge levels k >= 2048 of the network run through LDS: 11..13 barrier stages
-      // instead of 66..91
+    if (np >= 4 * WAVE * 4) {
+      // every wave sorts its quarter of the list in REGISTERS (runs of np / 4 keys, at most SORT_RUN_MAX: 4, 8 or 16 keys per
+      // lane, no barriers; odd runs descending = ascending sort of the complemented keys), then only the last merge levels of
+      // the network run through LDS: 19..25 barrier stages instead of 55..91.  (Before: runs of 1024 only, i.e. a list of 1100
+      // keys kept two of the four waves busy with 16-register sorts and lists of 513..1024 were sorted by ONE wave.)
       const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
-      for (int c = (int)wave; c < np / SORT_WAVE_MAX; c += (int)(blockDim.x / WAVE)) {
+      const int nw = (int)(blockDim.x / WAVE);
+      const int rl = min(SORT_RUN_MAX, np / nw);
+      for (int c = (int)wave; c < np / rl; c += nw) {
         const uint64_t flip = (c & 1) ? ~0ull : 0ull;
-        uint64_t key[SORT_WAVE_MAX / WAVE];
+        uint64_t *run = s_keys + (size_t)c * rl;
+        if (rl == 16 * WAVE) {
+          uint64_t key[16];
 #pragma unroll
-        for (int q = 0; q < SORT_WAVE_MAX / WAVE; q++) key[q] = s_keys[c * SORT_WAVE_MAX + q * WAVE + (int)lane] ^ flip;
-        wave_bitonic_sort<SORT_WAVE_MAX / WAVE>(key, lane);
+          for (int q = 0; q < 16; q++) key[q] = run[q * WAVE + (int)lane] ^ flip;
+          wave_bitonic_sort<16>(key, lane);
 #pragma unroll
-        for (int q = 0; q < SORT_WAVE_MAX / WAVE; q++) s_keys[c * SORT_WAVE_MAX + q * WAVE + (int)lane] = key[q] ^ flip;
+          for (int q = 0; q < 16; q++) run[q * WAVE + (int)lane] = key[q] ^ flip;
+        } else if (rl == 8 * WAVE) {
+          uint64_t key[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) key[q] = run[q * WAVE + (int)lane] ^ flip;
+          wave_bitonic_sort<8>(key, lane);
+#pragma unroll
+          for (int q = 0; q < 8; q++) run[q * WAVE + (int)lane] = key[q] ^ flip;
+        } else {
+          uint64_t key[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) key[q] = run[q * WAVE + (int)lane] ^ flip;
+          wave_bitonic_sort<4>(key, lane);
+#pragma unroll
+          for (int q = 0; q < 4; q++) run[q * WAVE + (int)lane] = key[q] ^ flip;
+        }
       }
       __syncthreads();
-      bitonic_sort_block(s_keys, np, 2 * SORT_WAVE_MAX);
+      bitonic_sort_block(s_keys, np, 2 * rl);
     } else if (np > 1) {
       bitonic_sort_block(s_keys, np);
     }
@@ -661,7 +682,7 @@ __device__ __forceinline__ void sort_big_tile(uint32_t tile, uint64_t *s_keys, c
   }
 }
 
-// Lists longer than SORT_WAVE_MAX: none at C3, most of the non-empty tiles of a close-up of a body.  The wave kernel leaves
+// Lists longer than SORT_WAVE_MAX (512): none at C3, most of the non-empty tiles of a close-up of a body.  The wave kernel leaves
 // their tile ids on a work list and a fixed grid of workgroups strides over that list: nothing but one counter read when the
 // list is empty, and an even share per workgroup wherever the long lists sit on the screen.  (One workgroup per tile: 5 us of
 // empty workgroups at C3; workgroups striding over the TILES: 113 instead of 50 us in the render() frame, because the tiles
@@ -788,7 +809,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   GSR_LAUNCH_CHECK(stream, debug);
   // (a separate 16 KB-LDS instantiation for 1025..2048 keys was measured: slower -- the register sorts of the runs, not the
   // LDS occupancy, bound this kernel)
-  const unsigned big_grid = 2u * (unsigned)cu_count();  // 64 KB of LDS each: two per CU
+  const unsigned big_grid = 4u * (unsigned)cu_count();  // SORT_BIG keys = 32 KB of LDS each: up to five per CU
   hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)(tiles < big_grid ? tiles : big_grid)), dim3(256),
                      0, stream, ranges, b.keys_a, b.vals_s, b.keys_s, b.tile_cursor, g.total + 2);
   GSR_LAUNCH_CHECK(stream, debug);
