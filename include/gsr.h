@@ -192,6 +192,21 @@ int gsr_alpha_mask_loss_backward(int width, int height, const float *color, cons
                                  const float *mask, float lambda_alpha, float *dL_dcolor, float *dL_dalpha,
                                  gsr_stream_t stream);
 
+/* gsr_rasterize_backward_ex with the image gradients of THAT loss formed inside the blend-backward kernel (per pixel, the same
+ * expressions) instead of read from three gradient images: out_color / out_alpha are the forward's images, gt [3][H][W],
+ * mask [1][H][W]; dL_ddepth = 0.  One launch and 48 B per pixel of traffic less than gsr_alpha_mask_loss_backward +
+ * gsr_rasterize_backward_ex; gradients bit-identical to that pair.  (No extra feature channels in this entry.) */
+int gsr_rasterize_backward_alpha_mask_loss(int P, int D, int M, int R, const float *background, int width, int height,
+                                           const float *means3D, const float *shs, const float *colors_precomp,
+                                           const float *out_alpha, const float *scales, float scale_modifier,
+                                           const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                                           const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy,
+                                           const int *radii, char *geom_buffer, char *binning_buffer, char *image_buffer,
+                                           const float *out_color, const float *gt, const float *mask, float lambda_alpha,
+                                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor,
+                                           float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
+                                           int debug, int sh_dtype, gsr_stream_t stream);
+
 /* Introspection of the private scratch buffers, for the parity tests only (copies device -> device):
  * what = one of GSR_Q_*; dst must hold the documented element count. */
 #define GSR_Q_DEPTHS 0        /* float[P]            geom  */

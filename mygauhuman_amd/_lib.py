@@ -19,7 +19,7 @@ SYMBOLS = [
     "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
-    "gsr_alpha_mask_loss_backward", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
+    "gsr_alpha_mask_loss_backward", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
     "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_backward_workgroups", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_step_status", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_model_activations_forward", "gsr_model_activations_backward", "gsr_frame_attributes_forward_split", "gsr_frame_attributes_backward_split",
 ]
@@ -79,7 +79,10 @@ def _load():
     lib.gsr_rasterize_forward_ex.argtypes = lib.gsr_rasterize_forward.argtypes[:-1] + [fp, C.c_int, fp, C.c_int, vp]
     lib.gsr_rasterize_forward_async_ex.argtypes = lib.gsr_rasterize_forward_async.argtypes[:-1] + [fp, C.c_int, fp, C.c_int, vp]
     lib.gsr_rasterize_backward_ex.argtypes = lib.gsr_rasterize_backward.argtypes[:-1] + [fp, C.c_int, C.POINTER(C.c_void_p), fp, C.c_int, vp]
-    for _n in ("gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex"):
+    lib.gsr_rasterize_backward_alpha_mask_loss.argtypes = (lib.gsr_rasterize_backward.argtypes[:24] + [fp, fp, fp, C.c_float] + [fp] * 9
+                                                           + [C.c_int, C.c_int, vp])
+    for _n in ("gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
+               "gsr_rasterize_backward_alpha_mask_loss"):
         getattr(lib, _n).restype = C.c_int
     lib.gsr_query_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_dist2_workspace_bytes.argtypes = [C.c_int]

@@ -163,11 +163,23 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     pyf[s] = (float)py;
     T[s] = inside ? a.final_T[p] : 0.f;
     lastc[s] = inside ? (int)a.n_contrib[p] : 0;
-    dpix0[s] = inside ? a.dL_dpix[p] : 0.f;
-    dpix1[s] = inside ? a.dL_dpix[plane + p] : 0.f;
-    dpix2[s] = inside ? a.dL_dpix[2 * plane + p] : 0.f;
-    ddep[s] = inside ? a.dL_ddepth[p] : 0.f;
-    dalp[s] = inside ? a.dL_dalpha[p] : 0.f;
+    if (a.loss_gt) {  // (kernel-uniform) fused alpha-mask loss: the pixel's gradient is formed here, see BlendBwdArgs
+      dpix0[s] = dpix1[s] = dpix2[s] = ddep[s] = dalp[s] = 0.f;
+      if (inside) {
+        const float d0 = a.loss_color[p] - a.loss_gt[p], d1 = a.loss_color[plane + p] - a.loss_gt[plane + p];
+        const float d2 = a.loss_color[2 * plane + p] - a.loss_gt[2 * plane + p];
+        dpix0[s] = d0 > 0.f ? a.loss_sc : (d0 < 0.f ? -a.loss_sc : 0.f);
+        dpix1[s] = d1 > 0.f ? a.loss_sc : (d1 < 0.f ? -a.loss_sc : 0.f);
+        dpix2[s] = d2 > 0.f ? a.loss_sc : (d2 < 0.f ? -a.loss_sc : 0.f);
+        dalp[s] = a.loss_sa * (a.loss_alpha[p] - a.loss_mask[p]);
+      }
+    } else {
+      dpix0[s] = inside ? a.dL_dpix[p] : 0.f;
+      dpix1[s] = inside ? a.dL_dpix[plane + p] : 0.f;
+      dpix2[s] = inside ? a.dL_dpix[2 * plane + p] : 0.f;
+      ddep[s] = inside ? a.dL_ddepth[p] : 0.f;
+      dalp[s] = inside ? a.dL_dalpha[p] : 0.f;
+    }
     float bgd = bg0 * dpix0[s] + bg1 * dpix1[s] + bg2 * dpix2[s];
     if (CE > 0) {
 #pragma unroll
@@ -801,7 +813,7 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     hipLaunchKernelGGL((blend_backward_kernel<1, 3, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
-  if (opt.blend_bwd_reduce == 2 && opt.blend_bwd_waves == 4) {
+  if (opt.blend_bwd_reduce == 2 && opt.blend_bwd_waves == 4 && !a.loss_gt) {  // (the MFMA experiment reads its image gradients)
     hipLaunchKernelGGL(blend_backward_mfma_kernel, dim3(tiles * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }

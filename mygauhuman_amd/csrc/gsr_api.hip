@@ -506,6 +506,15 @@ int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t 
                                         stream);
 }
 
+namespace {
+struct FusedLoss {
+  const float *color, *gt, *mask;
+  float lambda_alpha;
+};
+// set by gsr_rasterize_backward_alpha_mask_loss around its call of gsr_rasterize_backward_ex (same thread, same call)
+thread_local const FusedLoss *t_fused_loss = nullptr;
+}  // namespace
+
 int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
                               const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
                               float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
@@ -515,7 +524,7 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
                               float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                               float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
                               const float *const *dL_dout_extra, float *dL_dextra, int sh_dtype, gsr_stream_t stream_) {
-  (void)alphas;  // unused by the reference kernel as well (CR/backward.cu:410)
+  // alphas: unused by the reference kernel (CR/backward.cu:410); read by the fused alpha-mask loss only
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (P < 0 || R < 0 || width <= 0 || height <= 0) {
     set_error("gsr_rasterize_backward: bad sizes");
@@ -569,6 +578,11 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   ba.dL_dpix = dL_dpix;
   ba.dL_ddepth = dL_ddepths;
   ba.dL_dalpha = dL_dalphas;
+  if (t_fused_loss) {
+    ba.loss_color = t_fused_loss->color, ba.loss_alpha = alphas, ba.loss_gt = t_fused_loss->gt, ba.loss_mask = t_fused_loss->mask;
+    ba.loss_sc = 1.0f / (3.0f * (float)npix);
+    ba.loss_sa = 2.0f * t_fused_loss->lambda_alpha / (float)npix;
+  }
   ba.grad_rows = geom.grad_rows;
   ba.extra = extra_features;
   ba.CE = n_extra;
@@ -641,6 +655,31 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   if (rc != GSR_OK) return rc;
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;
+}
+
+int gsr_rasterize_backward_alpha_mask_loss(int P, int D, int M, int R, const float *background, int width, int height,
+                                           const float *means3D, const float *shs, const float *colors_precomp,
+                                           const float *out_alpha, const float *scales, float scale_modifier, const float *rotations,
+                                           const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                                           const float *campos, float tan_fovx, float tan_fovy, const int *radii, char *geom_buffer,
+                                           char *binning_buffer, char *image_buffer, const float *out_color, const float *gt,
+                                           const float *mask, float lambda_alpha, float *dL_dmean2D, float *dL_dconic,
+                                           float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                                           float *dL_dscale, float *dL_drot, int debug, int sh_dtype, gsr_stream_t stream) {
+  if (!out_color || !out_alpha || !gt || !mask) {
+    set_error("gsr_rasterize_backward_alpha_mask_loss: the rendered colour and alpha images, gt and mask are required");
+    return GSR_EINVAL;
+  }
+  const FusedLoss fl = {out_color, gt, mask, lambda_alpha};
+  t_fused_loss = &fl;
+  // (the three gradient-image arguments only have to be non-null: the kernel does not read them in this mode)
+  const int rc = gsr_rasterize_backward_ex(P, D, M, R, background, width, height, means3D, shs, colors_precomp, out_alpha, scales,
+                                           scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx,
+                                           tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_alpha, out_alpha,
+                                           dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                                           dL_drot, debug, nullptr, 0, nullptr, nullptr, sh_dtype, stream);
+  t_fused_loss = nullptr;
+  return rc;
 }
 
 int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,

@@ -212,6 +212,11 @@ struct BlendBwdArgs {
   const float *final_T;
   const uint32_t *n_contrib;
   const float *dL_dpix, *dL_ddepth, *dL_dalpha;
+  // loss_gt != null: the image gradients are those of the alpha-mask loss  mean|color - gt| + lambda mean (alpha - mask)^2  and
+  // are formed per pixel in the kernel's prologue (same expressions as loss.hip) instead of being read: dL_dpix = +-loss_sc,
+  // dL_dalpha = loss_sa (alpha - mask), dL_ddepth = 0; dL_dpix / dL_ddepth / dL_dalpha are not touched then
+  const float *loss_color, *loss_alpha, *loss_gt, *loss_mask;
+  float loss_sc, loss_sa;
   float *grad_rows;  // [P][GROW] (CE == 0) or [P][GROWX] (CE > 0), zeroed
   const float *extra;          // [P][CE]
   int CE;

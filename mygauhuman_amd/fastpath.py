@@ -92,6 +92,23 @@ class RasterSession:
             out["scales"].data_ptr(), out["rotations"].data_ptr(), 0, None, 0, None, None, sh_dtype, self._stream()),
             "gsr_rasterize_backward")
 
+    def backward_alpha_mask_loss(self, params, cam, bg, sh_degree, gt, mask, lambda_alpha, out, scale_modifier=1.0):
+        """backward() of the loss  mean|color - gt| + lambda_alpha * mean (alpha - mask)^2  of the last forward, with the loss
+        gradient formed inside the blend-backward kernel (no separate loss kernel, no gradient images): same gradients, bit
+        for bit, as alpha_mask_loss_backward() + backward()."""
+        p = params
+        sh_dtype = SH_F16 if p["shs"].dtype == torch.float16 else SH_F32
+        check(lib.gsr_rasterize_backward_alpha_mask_loss(
+            self.P, int(sh_degree), self.M, self.capacity, bg.data_ptr(), self.W, self.H, p["means3D"].data_ptr(),
+            p["shs"].data_ptr(), None, self.alpha.data_ptr(), p["scales"].data_ptr(), float(scale_modifier),
+            p["rotations"].data_ptr(), None, cam["viewmatrix"].data_ptr(), cam["projmatrix"].data_ptr(),
+            cam["campos"].data_ptr(), float(cam["tanfovx"]), float(cam["tanfovy"]), self.radii.data_ptr(),
+            self.geom.data_ptr(), self.bin.data_ptr(), self.img.data_ptr(), self.color.data_ptr(), gt.data_ptr(), mask.data_ptr(),
+            float(lambda_alpha), self.dL_dmean2D.data_ptr(), self.dL_dconic.data_ptr(), out["opacity"].data_ptr(),
+            self.dL_dcolors.data_ptr(), out["means3D"].data_ptr(), self.dL_dcov3D.data_ptr(), out["sh"].data_ptr(),
+            out["scales"].data_ptr(), out["rotations"].data_ptr(), 0, sh_dtype, self._stream()),
+            "gsr_rasterize_backward_alpha_mask_loss")
+
     # `status` may be a device tensor (default) or a pinned host tensor that the kernels write directly (ViewParallelStep)
     def _status_word(self, k):
         if not self.status.is_cuda:

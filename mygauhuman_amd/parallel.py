@@ -262,8 +262,9 @@ class ViewParallelStep:
             # mapped host memory) -- no bookkeeping kernel, no copy; the event below tells the host when they are there
             s.status = host
         s.forward(self.p, cam, bg, self.deg)
-        dc, da = s.alpha_mask_loss_backward(gt, mask, 0.1)
-        s.backward(self.p, cam, bg, self.deg, dc, s.dL_ddepth, da, self.grads)
+        # the loss gradient is formed inside the blend-backward kernel (fastpath.backward_alpha_mask_loss): no loss kernel, no
+        # gradient images
+        s.backward_alpha_mask_loss(self.p, cam, bg, self.deg, gt, mask, 0.1, self.grads)
         if reduce and self.world > 1:
             self._status(0)
             if self.compact is not None:

@@ -210,3 +210,38 @@ def test_c5_fp16_sh_at_500k():
     for k, v in res["f16"][4].items():
         assert np.isfinite(v).all() and float(np.abs(v).max()) > 1e-2, k
         util.assert_close(f"C5 fp16-SH {k}", v, res["f32"][4][k], tol=1e-5, max_bad_frac=1e-5)
+
+
+@pytest.mark.parametrize("P,W,H,deg", [(50_000, 512, 512, 0), (200_000, 1024, 1024, 3), (3000, 150, 70, 2)])
+def test_fused_alpha_mask_loss_backward_equals_loss_kernel_plus_backward(P, W, H, deg):
+    """session.backward_alpha_mask_loss forms the loss gradient inside the blend-backward kernel: the gradients must be those of
+    alpha_mask_loss_backward() + backward() -- bit for bit with the deterministic reduction, to summation order without."""
+    from mygauhuman_amd import _lib, synthetic
+    from mygauhuman_amd.fastpath import RasterSession
+    cam, g = synthetic.uniform_scene(P, W, H, seed=3, sh_degree=deg)
+    gt, mask = synthetic.loss_targets(W, H)
+    to = util.to_dev
+    M = (deg + 1) ** 2
+    params = dict(means3D=to(g["means3D"]), shs=to(g["shs"]), opacities=to(g["opacities"]), scales=to(g["scales"]), rotations=to(g["rotations"]))
+    camd = dict(cam, viewmatrix=to(cam["viewmatrix"]), projmatrix=to(cam["projmatrix"]), campos=to(cam["campos"]))
+    bg, gt_d, mask_d = to(np.array([0.1, 0.2, 0.3], np.float32)), to(gt), to(mask)
+    new_out = lambda: dict(means3D=torch.empty(P, 3, device="cuda"), sh=torch.empty(P, M, 3, device="cuda"),  # noqa: E731
+                           opacity=torch.empty(P, 1, device="cuda"), scales=torch.empty(P, 3, device="cuda"),
+                           rotations=torch.empty(P, 4, device="cuda"))
+    for det in (1, 0):
+        _lib.set_tuning("deterministic", det)
+        try:
+            s = RasterSession.calibrated(params, camd, bg, deg)
+            s.forward(params, camd, bg, deg)
+            a, b = new_out(), new_out()
+            dc, da = s.alpha_mask_loss_backward(gt_d, mask_d, 0.1)
+            s.backward(params, camd, bg, deg, dc, s.dL_ddepth, da, a)
+            s.backward_alpha_mask_loss(params, camd, bg, deg, gt_d, mask_d, 0.1, b)
+            for k in a:
+                assert float(a[k].abs().max()) > 0, k
+                if det:
+                    assert torch.equal(a[k], b[k]), k
+                else:
+                    util.assert_close(f"fused loss {k}", b[k].cpu().numpy(), a[k].cpu().numpy(), tol=2e-5, max_bad_frac=1e-5)
+        finally:
+            _lib.set_tuning("deterministic", 0)
