@@ -9,8 +9,8 @@ rank processes BEFORE anything touches the GPU and exits with their status.  Wit
 the ranks share device 0 over gloo: a functional rehearsal of the view-parallel path, labelled as such, not a scaling number.
 
 A step = one pass of the hot path over one synthetic camera view: rasterizer forward (preprocess -> binning ->
-blend), the alpha-mask loss gradient (L1(color, gt) + 0.1 MSE(alpha, mask), train.py:261-262), rasterizer backward
-(blend backward -> backward preprocess) and, for N > 1, the exchange of the Gaussian gradients (RCCL all-reduce of the
+blend), the alpha-mask loss gradient (L1(color, gt) + 0.1 MSE(alpha, mask), train.py:261-262; formed per pixel inside the
+blend-backward kernel, gsr_rasterize_backward_alpha_mask_loss), rasterizer backward (blend backward -> backward preprocess) and, for N > 1, the exchange of the Gaussian gradients (RCCL all-reduce of the
 flat bucket + compact SH all-gather).  Workload at N = 1: BASELINE.json configs[2] ("C3"): 200k Gaussians, SH degree 3,
 1024x1024, fp32, seeded synthetic scene of SURVEY.md §8(d) (S-uniform).  For N > 1 every rank renders its own view of the
 same replica (weak scaling).
