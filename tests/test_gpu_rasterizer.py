@@ -15,7 +15,9 @@ CASES = [
     (1, 48, 32, 2, 3, 0.05, 0.0),        # single Gaussian
     (20000, 256, 192, 3, 2, 0.01, 0.02),
     (700, 16, 16, 4, 1, 0.2, 0.0),       # one tile, everything overlaps, list longer than a batch
-    (9000, 24, 16, 5, 0, 0.3, 0.0),      # per-tile lists > 8192: the tile-bucket sort's merge path
+    (9000, 24, 16, 5, 0, 0.3, 0.0),      # per-tile lists > 4096: the tile-bucket sort's chunk + global-merge path
+    (1500, 16, 16, 6, 1, 0.2, 0.0),      # one list of 1025..2048 keys: four register runs of 512 + two LDS merge levels
+    (3000, 16, 16, 7, 0, 0.2, 0.0),      # one list of 2049..4096 keys: four register runs of 1024
 ]
 
 
@@ -218,8 +220,10 @@ def test_async_session_matches_sync_path_and_reports_overflow(oracle):
     assert torch.equal(color, c2) and torch.equal(alpha, a2) and torch.equal(radii, r2)
     dc = torch.sign(c2 - gt) / c2.numel()
     da = 0.2 * (a2 - mask) / a2.numel()
-    np.testing.assert_allclose(step.session.dL_dcolor.cpu().numpy(), dc.cpu().numpy(), rtol=0, atol=1e-12)
-    np.testing.assert_allclose(step.session.dL_dalpha.cpu().numpy(), da.cpu().numpy(), rtol=1e-6, atol=1e-12)
+    # (the step forms the loss gradient inside its backward kernel; the stand-alone loss kernel against the same expressions:)
+    k_dc, k_da = step.session.alpha_mask_loss_backward(gt, mask, 0.1)
+    np.testing.assert_allclose(k_dc.cpu().numpy(), dc.cpu().numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(k_da.cpu().numpy(), da.cpu().numpy(), rtol=1e-6, atol=1e-12)
     grads = _C.rasterize_gaussians_backward(bg, params["means3D"], r2, e, params["scales"], params["rotations"], 1.0, e,
                                             camd["viewmatrix"], camd["projmatrix"], cam["tanfovx"], cam["tanfovy"], dc,
                                             torch.zeros_like(a2), da, params["shs"], 3, camd["campos"], gb, R, bb, ib, a2, False)
