@@ -50,7 +50,7 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   bool inside[SLOTS];
   // "done" as a float folded into the alpha-threshold test (0 while the pixel is live, -1e30 once it is saturated or if it
   // lies outside the image): one v_add instead of a loop-carried lane mask and the scalar juggling that came with it
-  float dbias[SLOTS];
+  float dbias[SLOTS];  // (kept as the THRESHOLD of that test: -0.02 while live, +1e30 once done -- one add less per tested survivor)
   int pixid[SLOTS];
   // pixel rectangle of this wave (pixel centres), for the cull test
   const int q0 = (int)part * SLOTS, q1 = q0 + SLOTS - 1;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
     pxf[s] = (float)px;
     pyf[s] = (float)py;
     inside[s] = px < a.W && py < a.H;
-    dbias[s] = inside[s] ? 0.f : -1e30f;
+    dbias[s] = inside[s] ? -0.02f : 1e30f;
     pixid[s] = py * a.W + px;
     T[s] = 1.0f;
     C0[s] = C1[s] = C2[s] = Dp[s] = Wt[s] = 0.f;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   for (int base = 0; base < n; base += WAVE) {
     bool all_done = true;
 #pragma unroll
-    for (int s = 0; s < SLOTS; s++) all_done = all_done && (dbias[s] < 0.f);
+    for (int s = 0; s < SLOTS; s++) all_done = all_done && (dbias[s] > 0.f);
     if (__ballot(!all_done) == 0ull) break;
 
     // ---- fetch 64 list entries, cull against the wave's rectangle, compact the survivors into LDS
@@ -127,14 +127,14 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
         const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
         const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
         // cheap necessary condition for alpha >= 1/255:  log2(255*o) + power*log2(e) >= 0  (0.02 safety margin)
-        const bool pre = !(p2 > 0.0f) && ((p2 + g1.y) + dbias[s] >= -0.02f);
+        const bool pre = !(p2 > 0.0f) && ((p2 + g1.y) >= dbias[s]);
         if (__ballot(pre) != 0ull) {
           const float alpha = fminf(0.99f, g1.w * __builtin_amdgcn_exp2f(p2));
           const bool hit = pre && !(alpha < 1.0f / 255.0f);
           const float test_T = T[s] * (1.0f - alpha);
           const bool stop = hit && test_T < 0.0001f;
           const bool blend = hit && !stop;
-          dbias[s] = stop ? -1e30f : dbias[s];
+          dbias[s] = stop ? 1e30f : dbias[s];
           const float w = blend ? alpha * T[s] : 0.0f;
           C0[s] += g2.x * w;
           C1[s] += g2.y * w;
