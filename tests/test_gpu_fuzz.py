@@ -49,3 +49,4 @@ def test_random_scene_forward_backward(oracle, seed):
     for n in names:
         # (at least one element may sit on the tolerance: small tensors, float atomics in arbitrary order -- seed 85 of the long sweep)
         util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=max(3e-4, 1.5 / want[n].size))
+        util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=3e-4, max_bad_frac=3e-4 if want[n].size > 5000 else 0.0)  # and nothing far off
