@@ -507,15 +507,13 @@ int gsr_rasterize_forward_async(char *geom_buffer, char *binning_buffer, size_t 
 }
 
 namespace {
-struct FusedLoss {
+struct FusedLoss {  // gsr_rasterize_backward_alpha_mask_loss: the image gradients are formed in the blend-backward kernel
   const float *color, *gt, *mask;
   float lambda_alpha;
 };
-// set by gsr_rasterize_backward_alpha_mask_loss around its call of gsr_rasterize_backward_ex (same thread, same call)
-thread_local const FusedLoss *t_fused_loss = nullptr;
 }  // namespace
 
-int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
                               const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
                               float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
                               const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
@@ -578,10 +576,10 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   ba.dL_dpix = dL_dpix;
   ba.dL_ddepth = dL_ddepths;
   ba.dL_dalpha = dL_dalphas;
-  if (t_fused_loss) {
-    ba.loss_color = t_fused_loss->color, ba.loss_alpha = alphas, ba.loss_gt = t_fused_loss->gt, ba.loss_mask = t_fused_loss->mask;
+  if (fused_loss) {
+    ba.loss_color = fused_loss->color, ba.loss_alpha = alphas, ba.loss_gt = fused_loss->gt, ba.loss_mask = fused_loss->mask;
     ba.loss_sc = 1.0f / (3.0f * (float)npix);
-    ba.loss_sa = 2.0f * t_fused_loss->lambda_alpha / (float)npix;
+    ba.loss_sa = 2.0f * fused_loss->lambda_alpha / (float)npix;
   }
   ba.grad_rows = geom.grad_rows;
   ba.extra = extra_features;
@@ -657,6 +655,22 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
   return GSR_OK;
 }
 
+int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+                              const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
+                              float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                              const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
+                              char *geom_buffer, char *binning_buffer, char *image_buffer, const float *dL_dpix,
+                              const float *dL_ddepths, const float *dL_dalphas, float *dL_dmean2D, float *dL_dconic,
+                              float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                              float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
+                              const float *const *dL_dout_extra, float *dL_dextra, int sh_dtype, gsr_stream_t stream) {
+  return rasterize_backward_impl(nullptr, P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales,
+                                 scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
+                                 geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic,
+                                 dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, extra_features,
+                                 n_extra, dL_dout_extra, dL_dextra, sh_dtype, stream);
+}
+
 int gsr_rasterize_backward_alpha_mask_loss(int P, int D, int M, int R, const float *background, int width, int height,
                                            const float *means3D, const float *shs, const float *colors_precomp,
                                            const float *out_alpha, const float *scales, float scale_modifier, const float *rotations,
@@ -671,15 +685,12 @@ int gsr_rasterize_backward_alpha_mask_loss(int P, int D, int M, int R, const flo
     return GSR_EINVAL;
   }
   const FusedLoss fl = {out_color, gt, mask, lambda_alpha};
-  t_fused_loss = &fl;
   // (the three gradient-image arguments only have to be non-null: the kernel does not read them in this mode)
-  const int rc = gsr_rasterize_backward_ex(P, D, M, R, background, width, height, means3D, shs, colors_precomp, out_alpha, scales,
-                                           scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx,
-                                           tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, out_color, out_alpha, out_alpha,
-                                           dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                                           dL_drot, debug, nullptr, 0, nullptr, nullptr, sh_dtype, stream);
-  t_fused_loss = nullptr;
-  return rc;
+  return rasterize_backward_impl(&fl, P, D, M, R, background, width, height, means3D, shs, colors_precomp, out_alpha, scales,
+                                 scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
+                                 geom_buffer, binning_buffer, image_buffer, out_color, out_alpha, out_alpha, dL_dmean2D, dL_dconic,
+                                 dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, nullptr, 0, nullptr,
+                                 nullptr, sh_dtype, stream);
 }
 
 int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
