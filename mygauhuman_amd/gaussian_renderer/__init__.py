@@ -41,12 +41,12 @@ def _deform(pc, means3D, normal, cam, lbs_weights=None, correct_Rs=None, return_
     raise RuntimeError("render(): pc.SMPL_NEUTRAL (device tensors incl. kintree_table) is required for the LBS deform")
 
 
-def _features_of(pc, pipe):
+def _features_of(pc):
     """The SH coefficients for the attribute kernel: the model's two parameter tensors as they are (no torch.cat) when it has
     them in the reference's layout, get_features otherwise."""
     dc, rest = getattr(pc, "_features_dc", None), getattr(pc, "_features_rest", None)
-    if (dc is not None and rest is not None and not getattr(pipe, "property_activations", False) and dc.dim() == 3
-            and rest.dim() == 3 and dc.shape[1] == 1 and rest.shape[1] == 15 and dc.is_contiguous() and rest.is_contiguous()):
+    if (dc is not None and rest is not None and dc.dim() == 3 and rest.dim() == 3 and dc.shape[1] == 1 and rest.shape[1] == 15
+            and dc.is_contiguous() and rest.is_contiguous()):
         return (dc, rest)
     return pc.get_features
 
@@ -72,7 +72,7 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
 
     # the parameter activations: one fused kernel when the model offers it (scene_model.HumanGaussianModel.frame_activations),
     # the reference's property getters otherwise
-    act = pc.frame_activations() if (hasattr(pc, "frame_activations") and not getattr(pipe, "property_activations", False)) else None
+    act = pc.frame_activations() if hasattr(pc, "frame_activations") else None
     means3D = pc.get_xyz
     normal = act.normal if act is not None else pc.get_normal
     correct_Rs = None
@@ -111,7 +111,7 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
     sh_python = override_color is None and pipe.convert_SHs_python
     cov3D_precomp, colors_precomp, features = frame_attributes(
         means3D, transforms.reshape(-1, 3, 3), world_normal.reshape(-1, 3), scaling, scaling_modifier, pc._rotation,
-        rotation_n, albedo, roughness, _occlusion, _features_of(pc, pipe) if sh_python else None, pc.active_sh_degree,
+        rotation_n, albedo, roughness, _occlusion, _features_of(pc) if sh_python else None, pc.active_sh_degree,
         viewpoint_camera.camera_center, viewpoint_camera.world_view_transform)
 
     scales = rotations = shs = None

@@ -311,14 +311,15 @@ def test_render_step_as_one_graph_equals_eager(oracle):
 
 
 def test_render_with_fused_activations_equals_property_getters(oracle):
-    """render() reads the model through ONE activation kernel (HumanGaussianModel.frame_activations) by default;
-    `pipe.property_activations = True` goes through the reference-style property getters: same images, same gradients."""
+    """render() reads the model through ONE activation kernel (HumanGaussianModel.frame_activations) and the two SH tensors in
+    place when the model offers them; a model that only has the reference's property getters (util.GetterOnlyModel) goes
+    through the torch ops: same images, same gradients."""
     from mygauhuman_amd.gaussian_renderer import render
     outs, grads = {}, {}
     for prop in (False, True):
         s = _human_scene(oracle, seed=5)
-        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, property_activations=prop)
-        o = render(1, s.cam, s.model, pipe, util.to_dev(np.array([0.1, 0.2, 0.3], np.float32)))
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+        o = render(1, s.cam, util.GetterOnlyModel(s.model) if prop else s.model, pipe, util.to_dev(np.array([0.1, 0.2, 0.3], np.float32)))
         keys = ("render", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis", "render_alpha")
         sum(o[k].mean() * (i + 1) for i, k in enumerate(keys)).backward()
         outs[prop] = {k: o[k].detach().cpu().numpy() for k in keys + ("render_depth",)}

@@ -111,3 +111,17 @@ def assert_lists_are_sublists(f, ref_bin, tiles):
         assert all(a < b for a, b in zip(idx, idx[1:])), f"tile {t}: order differs from the reference list"
         kept += len(mine)
     return kept
+
+
+class GetterOnlyModel:
+    """A view of a HumanGaussianModel that offers render() only what the reference's GaussianModel offers: the property getters
+    (no frame_activations(), no direct access to the two SH parameter tensors) -- render() then takes its torch-op path."""
+    _HIDDEN = ("frame_activations", "_features_dc", "_features_rest")
+
+    def __init__(self, model):
+        object.__setattr__(self, "_m", model)
+
+    def __getattr__(self, name):
+        if name in GetterOnlyModel._HIDDEN:
+            raise AttributeError(name)
+        return getattr(object.__getattribute__(self, "_m"), name)

@@ -48,11 +48,12 @@ def main(P=200_000, V=6890, W=1024, H=1024, iters=120):
         densify.training_setup(model, dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=1.25e-4, opacity=0.05, scaling=5e-3, rotation=1e-3,
                                           normal=1e-3, albedo=0.05, roughness=0.05))
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep,
-                                     sync_free_raster=sync_free, property_activations=sep)  # reference structure: property getters
+                                     sync_free_raster=sync_free)
         # the "reference structure" variant also runs the torch op chain for the per-frame attributes
         import mygauhuman_amd.gaussian_renderer as gr
         from mygauhuman_amd.attributes import frame_attributes
         from tests.torch_reference import frame_attributes_torch, ssim_torch
+        from tests.util import GetterOnlyModel
         gr.frame_attributes = frame_attributes_torch if sep else frame_attributes
         bg = torch.zeros(3, device="cuda")
         gt = torch.rand((3, H, W), device="cuda")
@@ -61,7 +62,8 @@ def main(P=200_000, V=6890, W=1024, H=1024, iters=120):
         ssim = ssim_torch if sep else loss_utils.ssim
 
         def iteration(it):
-            o = render(it, cam, model, pipe, bg)
+            # reference structure: the model is read through its property getters (torch ops), like the reference's class
+            o = render(it, cam, GetterOnlyModel(model) if sep else model, pipe, bg)
             img, alpha, normal, axis = o["render"], o["render_alpha"], o["normal"], o["render_axis"]
             loss = (loss_utils.l1_loss(img, gt) + 0.1 * loss_utils.l2_loss(alpha, mask) + loss_utils.l1_loss(normal, gt_n) +
                     loss_utils.l1_loss(axis, gt_n) + 0.01 * (2.0 - ssim(img[None], gt[None]) - ssim(normal[None], gt_n[None])))
