@@ -74,6 +74,35 @@ def shape_offsets(smpl, shapes):
     return torch.matmul(sd, shapes.reshape(-1, 1)).squeeze(-1)
 
 
+class _FrameConstants:
+    """Results that depend only on tensors which stay the same frame after frame (a camera's big-pose parameters, a subject's
+    betas): recomputed only when one of the input tensors is another tensor or was written to.  Key = (address, version,
+    shape, device) of every input; the entry keeps the inputs alive, so an address cannot be handed to different data while
+    the entry lives.  Only used for inputs outside the autograd graph.  LRU."""
+
+    def __init__(self, capacity=4096):
+        from collections import OrderedDict
+        self.capacity, self.entries = capacity, OrderedDict()
+
+    def get(self, tag, smpl, tensors, compute):
+        if any(t.requires_grad for t in tensors) or torch.is_grad_enabled() and any(t.grad_fn is not None for t in tensors):
+            return compute()
+        key = (tag, id(smpl)) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in tensors)
+        hit = self.entries.get(key)
+        if hit is not None:
+            self.entries.move_to_end(key)
+            return hit[1]
+        with torch.no_grad():
+            value = compute()
+        self.entries[key] = ((smpl,) + tuple(tensors), value)
+        if len(self.entries) > self.capacity:
+            self.entries.popitem(last=False)
+        return value
+
+
+_CONSTANTS = _FrameConstants()
+
+
 def parents_host(smpl):
     """Kinematic-tree parents as a host tuple, read from the device once per SMPL dict (the reference indexes the device
     tensor joint by joint: 23 blocking reads per chain)."""
@@ -143,7 +172,9 @@ def smpl_pose_transforms(smpl, params, correct_Rs=None):
             Js = torch.einsum("jv,vcl->jcl", smpl["J_regressor"], smpl["shapedirs"][..., :nb].float())       # [24, 3, nb]
         cache = (nb, Jt.contiguous(), Js.contiguous())
         smpl["_joint_tables"] = cache
-    joints = cache[1] + torch.matmul(cache[2], betas.reshape(-1, 1).float()).squeeze(-1)
+    # (a subject's betas are the same tensor frame after frame: the small product is cached on it)
+    joints = _CONSTANTS.get("joints", smpl, (betas,),
+                            lambda: cache[1] + torch.matmul(cache[2], betas.reshape(-1, 1).float()).squeeze(-1))
     rot, A = _SmplPose.apply(params["poses"], correct_Rs, joints, parents_host(smpl))
     return A[None], rot[None], joints[None]
 
@@ -264,11 +295,17 @@ def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_we
     (smpl_src_pts[1,P,3], world_src_pts[1,P,3], bweights[1,P,24], transforms[1,P,3,3], translation|None, world_normals)."""
     assert query_pts.shape[0] == 1, "batch size 1 (like every call site of the reference)"
     # big pose -> T pose, T pose -> target pose: one single-wave kernel each (csrc/pose.hip)
-    A_big, rot_big, _ = smpl_pose_transforms(smpl, t_params)
+    # the big-pose side depends on the camera's big_pose_smpl_param alone, the shape offsets on the subject's betas: both are
+    # the same tensors frame after frame (scene/cameras.py:44-74) and are computed once per tensor (pose kernel + 17 MB
+    # pose-blend-shape product + two small rocBLAS products per frame otherwise)
+    def big_pose():
+        A, rot, _ = smpl_pose_transforms(smpl, t_params)
+        return A, pose_offsets(smpl, rot)
+    A_big, off_big = _CONSTANTS.get("big_pose", smpl, (t_params["poses"], t_params["shapes"]), big_pose)
     A_pose, rot_mats, _ = smpl_pose_transforms(smpl, params, correct_Rs)
     R, Th = params["R"], params["Th"]
-    off_big = pose_offsets(smpl, rot_big)
-    off_shape = shape_offsets(smpl, params["shapes"].to(query_pts.device))
+    shapes = params["shapes"].to(query_pts.device)
+    off_shape = _CONSTANTS.get("shape_offsets", smpl, (shapes,), lambda: shape_offsets(smpl, shapes))
     off_pose = pose_offsets(smpl, rot_mats)
     o = lbs_deform(query_pts[0], None if normals is None else normals[0], None if lbs_weights is None else lbs_weights[0],
                    A_big[0], A_pose[0], off_big, off_shape, off_pose, R.reshape(3, 3), Th.reshape(-1)[:3], t_vertices[0],

@@ -92,6 +92,26 @@ def test_coarse_deform_c2source_matches_oracle_pipeline(oracle):
     np.testing.assert_allclose(transl[0].cpu().numpy(), want["translation"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(wn[0].cpu().numpy(), want["world_normals"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(smpl_src[0].cpu().numpy(), want["smpl_src"], rtol=1e-4, atol=1e-4)
+    # the big-pose side and the shape offsets are cached on their (frame-constant) input tensors: a second call reuses them and
+    # gives the same bits, an in-place change of an input (version bump) recomputes
+    n0 = len(lbs._CONSTANTS.entries)
+    again = lbs.coarse_deform_c2source(smpl, d(c["query"][None]), params, t_params, d(c["big_verts"][None]),
+                                       lbs_weights=d(c["loff"][None]), return_transl=True, normals=d(c["normals"][None]))
+    assert len(lbs._CONSTANTS.entries) == n0 and torch.equal(again[1], world) and torch.equal(again[3], tf)
+    t_params["poses"].mul_(0.5)
+    params["shapes"].add_(0.25)
+    moved = lbs.coarse_deform_c2source(smpl, d(c["query"][None]), params, t_params, d(c["big_verts"][None]),
+                                       lbs_weights=d(c["loff"][None]), return_transl=True, normals=d(c["normals"][None]))
+    fresh_t = {k: v.clone() for k, v in t_params.items()}
+    fresh_p = {k: v.clone() for k, v in params.items()}
+    fresh = lbs.coarse_deform_c2source(smpl, d(c["query"][None]), fresh_p, fresh_t, d(c["big_verts"][None]),
+                                       lbs_weights=d(c["loff"][None]), return_transl=True, normals=d(c["normals"][None]))
+    assert not torch.equal(moved[1], world) and torch.equal(moved[1], fresh[1]) and torch.equal(moved[3], fresh[3])
+    # inputs inside the autograd graph are never cached
+    t_grad = dict(t_params, poses=t_params["poses"].clone().requires_grad_(True))
+    n1 = len(lbs._CONSTANTS.entries)
+    lbs.coarse_deform_c2source(smpl, d(c["query"][None]), params, t_grad, d(c["big_verts"][None]))
+    assert len(lbs._CONSTANTS.entries) == n1
 
 
 def _torch_deform(query, normals, loff, A_big, A_pose, off_big, off_shape, off_pose, R, Th, ids, weights):
