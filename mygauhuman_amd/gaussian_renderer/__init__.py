@@ -55,11 +55,9 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
            return_smpl_rot=False, transforms=None, translation=None, envmap=None):
     """Render the scene. Background tensor (bg_color) must be on the GPU."""
     dev = pc.get_xyz.device
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:  # noqa: BLE001
-        pass
+    # the gradient holder of the 2D means (:62-66: `zeros_like(...) + 0` and retain_grad()): a zero LEAF that requires grad
+    # receives the same .grad without the extra add kernel
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
