@@ -790,6 +790,276 @@ int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t 
   return GSR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 18-channel (fused multi-feature) backward with its reductions through LDS (knob blend_bwd_reduce = 3, the default).
+//
+// blend_backward_kernel<1, 0, 18> above folds every channel sum with permlane swaps and DPP (~80 FMA slots per colour triple
+// per four Gaussians on top of ~130 for the nine base sums) and sits at 108 VGPRs / 8 KB of LDS.  Here the base sums take the
+// two LDS hops of the plain kernel, and the channel sums reuse the first hop: the reducer lane (row = Gaussian, c = column)
+// already holds the blending weights w of "its" four pixels c + 16 q, so a channel's column-partial sum is four FMAs against
+// that channel's image gradient at those four pixels -- a per-wave table s_dx[channel][c][q] written once in the prologue
+// (only the channels of the 6-bit image mask, dynamic LDS) -- and the 16 column partials of a row meet in a second hop
+// (one triple at a time: three 4-byte stores, then lanes (row, k < 3) add sixteen values each).  LDS budget: survivors are
+// staged 32 at a time (half the plain kernel's batch) so that records + channel colours + transposition buffer + table stay
+// below 10 KB per wave for up to ~8 live channels: the occupancy curve in DESIGN.md punishes every wave lost.
+constexpr int FB = 32;                 // survivors staged at a time
+constexpr int FX_LROW = 12;            // floats per pixel lane in the transposition buffer (as LFOLD above)
+constexpr int FX_BASE2 = 4 * 2 * 5 * 8;  // floats of the base sums' second hop
+constexpr int FX_TRI2 = 4 * 3 * 16;      // floats of one colour triple's second hop
+
+__global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const BlendBwdArgs a) {
+  constexpr int CE = CE_MAX, NT = CE / 3;
+  __shared__ __attribute__((aligned(16))) float s_rw[WAVE * FX_LROW];  // 768 floats: hop 1; hop 2: base [0, 320) + one triple [320, 512)
+  __shared__ __attribute__((aligned(16))) float s_x[FB * CE];
+  __shared__ float4 s0[FB], s1[FB], s2[FB];
+  __shared__ uint32_t s_id[FB + 4];
+  extern __shared__ __attribute__((aligned(16))) float s_dx[];  // [live channel][c = pixel & 15][q = pixel >> 4]
+  static_assert(FX_BASE2 + FX_TRI2 <= WAVE * FX_LROW, "second-hop regions must fit the transposition buffer");
+
+  const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);
+  const uint32_t tile = item / 4, part = item % 4;
+  const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+  const uint32_t lane = threadIdx.x;
+  const uint2 range = a.ranges[tile];
+  const int n = (int)(range.y - range.x);
+  const size_t plane = (size_t)a.H * a.W;
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  const uint32_t mask = a.extra_mask;
+
+  const int q0 = (int)part;
+  const float rx0 = (float)(tx * TILE + (q0 & 1) * 8), rx1 = rx0 + 7.f;
+  const float ry0 = (float)(ty * TILE + (q0 >> 1) * 8), ry1 = ry0 + 7.f;
+  const int px = tx * TILE + (q0 & 1) * 8 + (int)(lane & 7), py = ty * TILE + (q0 >> 1) * 8 + (int)(lane >> 3);
+  const bool inside = px < a.W && py < a.H;
+  const int p = py * a.W + px;
+  const float pxf = (float)px, pyf = (float)py;
+  float T = inside ? a.final_T[p] : 0.f;
+  const int lastc = inside ? (int)a.n_contrib[p] : 0;
+  const float dpix0 = inside ? a.dL_dpix[p] : 0.f, dpix1 = inside ? a.dL_dpix[plane + p] : 0.f;
+  const float dpix2 = inside ? a.dL_dpix[2 * plane + p] : 0.f;
+  const float ddep = inside ? a.dL_ddepth[p] : 0.f, dalp = inside ? a.dL_dalpha[p] : 0.f;
+  float bgd = bg0 * dpix0 + bg1 * dpix1 + bg2 * dpix2;
+  float dxp[CE];
+  {
+    int ci = 0;  // index among the live channels (wave-uniform)
+#pragma unroll
+    for (int c = 0; c < CE; c++) {
+      const bool on = (mask >> (c / 3)) & 1u;
+      dxp[c] = (on && inside) ? a.dL_dextra_tri[c / 3][(size_t)(c % 3) * plane + p] : 0.f;
+      bgd += (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2)) * dxp[c];
+      if (on) {
+        s_dx[ci * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dxp[c];
+        ci++;
+      }
+    }
+  }
+  const float Tb = T * bgd;  // T_final * (bg . dL_dpix), over every colour channel
+  float X = 0.f;
+  int maxlast = lastc;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxlast = max(maxlast, __shfl_xor(maxlast, d, WAVE));
+  const int skip = n - maxlast;  // list entries at front positions >= maxlast contribute to none of this wave's pixels
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int row = (int)(lane >> 4), kcol = (int)(lane & 15);
+  const bool upper = (lane & 8u) != 0;
+  const int jj = (int)(lane & 7u);
+  float dps[4][3];  // dL_dpix of the four pixels (lane & 15) + 16 q this lane sums as a reader
+  s_rw[lane * 4 + 0] = dpix0;
+  s_rw[lane * 4 + 1] = dpix1;
+  s_rw[lane * 4 + 2] = dpix2;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float4 t4 = *reinterpret_cast<const float4 *>(&s_rw[((lane & 15) + 16 * q) * 4]);
+    dps[q][0] = t4.x;
+    dps[q][1] = t4.y;
+    dps[q][2] = t4.z;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  for (int base = skip; base < n; base += WAVE) {
+    // ---- fetch 64 entries (from the back), cull; the survivors go through LDS in back-to-front order, FB at a time
+    const int idx = base + (int)lane;
+    bool keep = false;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    uint32_t id = 0;
+    if (idx < n) {
+      id = a.point_list[range.y - 1 - idx];
+      const float4 *src = reinterpret_cast<const float4 *>(a.recs + id);
+      r0 = src[0];
+      r2 = src[2];
+      keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
+      if (keep) {
+        r1 = src[1];
+        keep = ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rx0, rx1, ry0, ry1);
+      }
+    }
+    const uint64_t kmask = __ballot(keep);
+    const int cnt = __builtin_popcountll(kmask);
+    const int slot = __builtin_popcountll(kmask & lt);
+    for (int h0 = 0; h0 < cnt; h0 += FB) {
+      if (keep && slot >= h0 && slot < h0 + FB) {
+        const int sl = slot - h0;
+        constexpr float L2E = 1.4426950408889634f;
+        s0[sl] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
+        s1[sl] = make_float4((-0.5f * L2E) * r1.x, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)), r1.y);
+        s2[sl] = make_float4(r1.w, r2.x, r2.y, r1.z);
+        s_id[sl] = id;
+        const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
+#pragma unroll
+        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[sl * CE])[q] = xs[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int m = min(FB, cnt - h0);
+      for (int g = 0; g < m; g += 4) {
+        float accr[4], accw[4];
+        uint32_t anyhit = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          accr[u] = 0.f;
+          accw[u] = 0.f;
+          if (g + u < m) {  // wave-uniform
+            const float4 g0 = s0[g + u];
+            const float4 g1 = s1[g + u];
+            const int fpos = (int)__float_as_uint(g1.z);  // 0-based position from the front
+            const float dx = g0.x - pxf, dy = g0.y - pyf;
+            const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
+            const bool pre = (fpos < lastc) && !(p2 > 0.0f) && (p2 + g1.y >= -0.02f);
+            if (__ballot(pre) != 0ull) {  // wave-uniform: some lane may reach alpha >= 1/255
+              // select form (see blend_backward_kernel): lanes that are not hit run with alpha = G = 0, every update a no-op
+              const float4 g2 = s2[g + u];
+              const float G0 = __builtin_amdgcn_exp2f(p2);
+              const float alpha0 = fminf(0.99f, g1.w * G0);
+              const bool hit = pre && !(alpha0 < 1.0f / 255.0f);
+              const float alpha = hit ? alpha0 : 0.f, G = hit ? G0 : 0.f;
+              const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+              const float Tn = T * rc;  // transmittance in front of this Gaussian
+              const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
+              float e = g2.x * dpix0 + g2.y * dpix1 + g2.z * dpix2 + g2.w * ddep + dalp;
+#pragma unroll
+              for (int t = 0; t < NT; t++)
+                if ((mask >> t) & 1u) {  // wave-uniform
+#pragma unroll
+                  for (int c = 3 * t; c < 3 * t + 3; c++) e += s_x[(g + u) * CE + c] * dxp[c];
+                }
+              const float dL_dalpha = Tn * e - (X + Tb) * rc;
+              X += w * e;
+              T = Tn;
+              accr[u] = G * dL_dalpha;
+              accw[u] = w;
+              anyhit |= 1u << u;
+            }
+          }
+        }
+        if (anyhit) {  // wave-uniform
+          const bool row_live = ((anyhit >> row) & 1u) && (g + row < m);
+          const uint32_t gid = row_live ? s_id[g + row] : 0u;
+          const float2 gxy = *reinterpret_cast<const float2 *>(&s0[min(g + row, FB - 1)]);  // this row's Gaussian centre
+          const float dxr = gxy.x - pxf;                                                      // against this lane's column
+          // ---- hop 1: (r, w) of the four Gaussians, pixel lanes -> reducer lanes (row = Gaussian, c = lane & 15)
+          *reinterpret_cast<float4 *>(&s_rw[lane * FX_LROW]) = make_float4(accr[0], accw[0], accr[1], accw[1]);
+          *reinterpret_cast<float4 *>(&s_rw[lane * FX_LROW + 4]) = make_float4(accr[2], accw[2], accr[3], accw[3]);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          float2 rw[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) rw[q] = *reinterpret_cast<const float2 *>(&s_rw[((int)(lane & 15) + 16 * q) * FX_LROW + 2 * row]);
+          __builtin_amdgcn_wave_barrier();  // the second-hop stores below stay behind these reads
+          // ---- base sums (as the LFOLD branch of blend_backward_kernel)
+          const float hh = upper ? 1.f : 0.f;
+          const float e0 = (rw[0].x + rw[1].x) + (rw[2].x + rw[3].x);
+          const float A1 = rw[1].x + 2.f * rw[2].x + 3.f * rw[3].x;   // sum q r
+          const float A2 = rw[1].x + 4.f * rw[2].x + 9.f * rw[3].x;   // sum q^2 r
+          const float s1y = 2.f * A1 + hh * e0;                       // sum ly r
+          const float s2y = 4.f * A2 + hh * (4.f * A1 + e0);          // sum ly^2 r   (h^2 = h)
+          const float Dy = gxy.y - (pyf - (float)(lane >> 3));        // mean.y - top pixel row of the quadrant
+          float c[6];
+          c[0] = e0;
+          c[1] = Dy * e0 - s1y;
+          c[2] = Dy * (Dy * e0 - 2.f * s1y) + s2y;
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++)
+            c[3 + ch] = (rw[0].y * dps[0][ch] + rw[1].y * dps[1][ch]) + (rw[2].y * dps[2][ch] + rw[3].y * dps[3][ch]);
+          const float qa = pack_halves(c[0], c[1], upper);
+          const float qb = qa * dxr;
+          const float c2 = c[2] + dpp_f<0x128>(c[2]);
+          const float qc = upper ? c2 : qb * dxr;
+          const float ka = pack_halves(c[3], c[4], upper);
+          const float kb = c[5] + dpp_f<0x128>(c[5]);
+          float *t2 = &s_rw[((row * 2 + (upper ? 1 : 0)) * 5) * 8 + jj];
+          t2[0] = qa;
+          t2[8] = qb;
+          t2[16] = qc;
+          t2[24] = ka;
+          t2[32] = kb;
+          // ---- channel sums of the first live triple ride with the base sums' second hop; further triples take turns
+          int ci = 0;
+          bool base_done = false;
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+            if (!((mask >> t) & 1u)) continue;  // wave-uniform
+            float x3[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              const float4 d4 = *reinterpret_cast<const float4 *>(&s_dx[(ci + j) * WAVE + (int)(lane & 15u) * 4]);
+              x3[j] = (rw[0].y * d4.x + rw[1].y * d4.y) + (rw[2].y * d4.z + rw[3].y * d4.w);
+            }
+            ci += 3;
+            float *t3 = &s_rw[FX_BASE2 + (row * 3) * 16 + (int)(lane & 15u)];
+            t3[0] = x3[0];
+            t3[16] = x3[1];
+            t3[32] = x3[2];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!base_done) {
+              base_done = true;
+              constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;  // bit k: upper half (see blend_backward_kernel)
+              constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;   // nibble k: which of qa..kb (0..4)
+              const int k9 = kcol < 9 ? kcol : 0;
+              const int hk = (int)((HALF_OF_K >> k9) & 1u), vk = (int)((VAL_OF_K >> (4 * k9)) & 0xFu);
+              const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2 + hk) * 5 + vk) * 8]);
+              const float4 lo4 = src8[0], hi4 = src8[1];
+              const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
+              if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + kcol], vsum);
+            }
+            {
+              const int k3 = kcol < 3 ? kcol : 0;
+              const float4 *src16 = reinterpret_cast<const float4 *>(&s_rw[FX_BASE2 + (row * 3 + k3) * 16]);
+              const float4 v0 = src16[0], v1 = src16[1], v2 = src16[2], v3 = src16[3];
+              const float xs = (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) +
+                               (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
+              if (row_live && kcol < 3) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + NACC + 3 * t + kcol], xs);
+            }
+            __builtin_amdgcn_wave_barrier();  // the next triple's (or the next group's) stores stay behind these reads
+          }
+          if (!base_done) {  // no live triple at all: the base sums' second hop alone
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;
+            constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;
+            const int k9 = kcol < 9 ? kcol : 0;
+            const int hk = (int)((HALF_OF_K >> k9) & 1u), vk = (int)((VAL_OF_K >> (4 * k9)) & 0xFu);
+            const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2 + hk) * 5 + vk) * 8]);
+            const float4 lo4 = src8[0], hi4 = src8[1];
+            const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
+            if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + kcol], vsum);
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // keep the next half's LDS writes behind this half's reads
+    }
+  }
+}
+
+
 int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
@@ -805,6 +1075,11 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     if (a.CE != CE_MAX || !a.extra) {
       set_error("fused feature blend backward: exactly %d extra channels with their arrays are required", CE_MAX);
       return GSR_EINVAL;
+    }
+    if (opt.blend_bwd_reduce == 3) {  // reductions through LDS; dynamic LDS = the image-gradient table of the live channels
+      const unsigned live = 3u * (unsigned)__builtin_popcount(a.extra_mask & 0x3Fu);
+      hipLaunchKernelGGL(blend_backward_features_kernel, dim3(tiles * 4), dim3(WAVE), (live ? live : 1u) * WAVE * sizeof(float), stream, a);
+      return GSR_OK;
     }
     hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;

@@ -39,7 +39,7 @@ def main(P=200_000, V=6890, W=1024, H=1024):
     bp = dict(poses=d(big[None]), shapes=d(np.zeros((1, 10), np.float32)), R=d(np.eye(3, dtype=np.float32)), Th=d(np.zeros((1, 3), np.float32)))
     cam = cameras.ViewCamera(cam_np, "cuda", sp, bp, d(vt))
     bg = torch.zeros(3, device="cuda")
-    for sep, keys in ((False, PHASE1_KEYS if os.environ.get("KEYS") == "phase1" else ALL_KEYS),) if os.environ.get("PROFILE") else (((False, PHASE1_KEYS), (False, ALL_KEYS), (False, PHASE1_KEYS), (False, ALL_KEYS)) if os.environ.get("ORDER") else ((False, ALL_KEYS), (False, PHASE1_KEYS), (True, ALL_KEYS))):
+    for sep, keys in ((False, PHASE1_KEYS if os.environ.get("KEYS") == "phase1" else ALL_KEYS),) if (os.environ.get("PROFILE") or os.environ.get("ONLY")) else (((False, PHASE1_KEYS), (False, ALL_KEYS), (False, PHASE1_KEYS), (False, ALL_KEYS)) if os.environ.get("ORDER") else ((False, ALL_KEYS), (False, PHASE1_KEYS), (True, ALL_KEYS))):
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep, sync_free_raster=os.environ.get("SYNC_FREE", "1") != "0")
 
         def step():
