@@ -74,28 +74,37 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
   }
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
+  // Two-stage prefetch of the list: while batch b is blended, the records of batch b + 1 and the list entries of batch b + 2 are
+  // already on their way (a close-up of a body keeps only ~800 of the 4096 tiles busy: three waves per SIMD, each walking
+  // ~25 batches, cannot hide a point_list -> record load chain per batch behind one another)
+  uint32_t id_a = 0, id_b = 0;  // list entries of the NEXT batch / of the one after it
+  float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;  // records of the current batch (prefetched)
+  uint32_t id_cur = 0;
+  if ((int)lane < n) {
+    id_cur = a.point_list[range.x + lane];
+    const float4 *src = reinterpret_cast<const float4 *>(a.recs + id_cur);
+    p0 = src[0];
+    p1 = src[1];
+    p2 = src[2];
+  }
+  if ((int)lane + WAVE < n) id_a = a.point_list[range.x + lane + WAVE];
   for (int base = 0; base < n; base += WAVE) {
     bool all_done = true;
 #pragma unroll
     for (int s = 0; s < SLOTS; s++) all_done = all_done && (dbias[s] > 0.f);
     if (__ballot(!all_done) == 0ull) break;
 
-    // ---- fetch 64 list entries, cull against the wave's rectangle, compact the survivors into LDS
+    // ---- this batch's 64 list entries (already in registers), the next batches' loads, cull against the wave's rectangle,
+    // compact the survivors into LDS
     const int idx = base + (int)lane;
+    const float4 r0 = p0, r1c = p1, r2 = p2;
+    const uint32_t id = id_cur;
+    (void)id_b;
     bool keep = false;
-    float4 r0 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
-    const float4 *src = nullptr;
-    uint32_t id = 0;
-    if (idx < n) {
-      id = a.point_list[range.x + idx];
-      src = reinterpret_cast<const float4 *>(a.recs + id);
-      r0 = src[0];
-      r2 = src[2];
-      keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
-    }
+    if (idx < n) keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
     float4 r1 = make_float4(0, 0, 0, 0);
     if (keep) {  // second, exact filter: ellipse {alpha >= 1/255} against the wave's pixel rectangle
-      r1 = src[1];
+      r1 = r1c;
       keep = ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rx0, rx1, ry0, ry1);
     }
     const uint64_t kmask = __ballot(keep);
@@ -113,6 +122,17 @@ __global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs 
         for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[slot * CE])[q] = xs[q];
       }
     }
+    // the next batch's records and the list entries of the batch after it go out AFTER this batch's channel-colour loads
+    // (loads retire in order: waiting for those must not wait for these).  (Prefetching the channel colours of the next batch
+    // as well -- 18 more registers, for survivors or not -- was slower: 221 vs 209 us in the render() frame.)
+    id_cur = id_a;
+    if (idx + WAVE < n) {
+      const float4 *src = reinterpret_cast<const float4 *>(a.recs + id_a);
+      p0 = src[0];
+      p1 = src[1];
+      p2 = src[2];
+    }
+    if (idx + 2 * WAVE < n) id_a = a.point_list[range.x + idx + 2 * WAVE];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
