@@ -51,8 +51,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void bucket_count_kernel(const GeomState
 // body of the tile scan for ONE workgroup of 1024 threads
 __device__ __forceinline__ void tile_scan_block(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n, const uint32_t *total,
                                                 uint32_t capacity, uint32_t *status, int CSTRIDE, int check_prefilter,
-                                                uint32_t *wtot, uint32_t *carry_s) {
+                                                uint32_t *wtot, uint32_t *carry_s, uint32_t *order) {
   const uint32_t R = *total;
+  if (threadIdx.x == 0 && order) order[n] = 0u;  // natural tile order for the blend kernels (only the histogram path reorders)
   if (threadIdx.x == 0 && status) {
     status[0] = R;
     status[1] = (R > capacity ? 1u : 0u) | ((check_prefilter && total[1]) ? 2u : 0u);
@@ -89,10 +90,10 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *counts, uint32_t
 }
 __global__ __launch_bounds__(1024) void bucket_scan_kernel(const uint32_t *counts, uint32_t *cursor, uint2 *ranges, int n,
                                                           const uint32_t *total, uint32_t capacity, uint32_t *status, int CSTRIDE,
-                                                          int check_prefilter) {
+                                                          int check_prefilter, uint32_t *order) {
   __shared__ uint32_t wtot[1024 / WAVE];
   __shared__ uint32_t carry_s;
-  tile_scan_block(counts, cursor, ranges, n, total, capacity, status, CSTRIDE, check_prefilter, wtot, &carry_s);
+  tile_scan_block(counts, cursor, ranges, n, total, capacity, status, CSTRIDE, check_prefilter, wtot, &carry_s, order);
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void bucket_scatter_kernel(const GeomState g, const int *radii, int P, int gx, int gy,
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(PW *WAVE) void bucket_hist_prefix_kernel(uint32_t *
 __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, const uint32_t *wg_start, int tiles,
                                                                 const uint32_t *totals, const uint32_t *table, const uint32_t *rank,
                                                                 const uint32_t *gids, uint64_t *bucket, uint32_t capacity,
-                                                                uint2 *ranges, uint32_t *status, int check_prefilter) {
+                                                                uint2 *ranges, uint32_t *status, int check_prefilter, uint32_t *order) {
   constexpr int PER_MAX = (HIST_MAX_TILES + HB - 1) / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
@@ -327,8 +328,10 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     }
   }
   if (R > capacity) {  // overflow: nothing is binned, every tile is empty (the caller reads the status words and regrows)
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
       for (int t = threadIdx.x; t < tiles; t += HB) ranges[t] = make_uint2(0u, 0u);
+      if (threadIdx.x == 0) order[tiles] = 0u;
+    }
     return;
   }
   const uint32_t *row = table + (size_t)blockIdx.x * tiles;
@@ -366,6 +369,97 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     const uint32_t gid = gids[inst];
     const uint32_t dbits = __float_as_uint(g.recs[gid].depth);
     bucket[s_base[r >> 16] + (r & 0xFFFFu)] = ((uint64_t)dbits << 32) | (uint64_t)gid;
+  }
+  // ---- visiting order of the tiles for the blend kernels (the last workgroup, which has the least scatter work left to hide
+  // it behind... any single workgroup will do): tiles whose list is much longer than the average go FIRST.  A wave walks its
+  // list serially (a dependent chain per survivor), so the kernel cannot end before its longest list has been walked from
+  // wherever that wave STARTED: in a close-up of a body (1,480 busy tiles, lists up to 3x the mean) the long lists of the
+  // lower image rows started after the first round of waves had retired.  Balanced scenes (C3: no list above 2x the mean)
+  // keep the natural order and its L2 locality (flag word 0).
+  if (blockIdx.x != gridDim.x - 1) return;
+  __shared__ uint32_t s_red[HB / WAVE][2];
+  __shared__ uint32_t s_cls[HB / WAVE][3];
+  __shared__ uint32_t s_thr;
+  uint32_t busy = 0, mx = 0;
+#pragma unroll
+  for (int k = 0; k < PER_MAX; k++) {
+    busy += cnt[k] ? 1u : 0u;
+    mx = max(mx, cnt[k]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    busy += __shfl_xor(busy, d, WAVE);
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
+  }
+  __syncthreads();  // (s_wtot is read above by the other waves until here)
+  if (lane == 0) {
+    s_red[wave][0] = busy;
+    s_red[wave][1] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t b = 0, m = 0, all = 0;
+    for (int w = 0; w < HB / WAVE; w++) {
+      b += s_red[w][0];
+      m = max(m, s_red[w][1]);
+      all += s_wtot[w];  // (the waves' sums of the tile totals, from the scan above)
+    }
+    const uint32_t mean = b ? all / b : 0u;
+    const uint32_t thr = mean + mean / 2u + 1u;  // "long" = more than 1.5 x the mean list of the busy tiles
+    const bool unbalanced = m >= 2u * mean + 1u; // reorder only if some list is more than twice the mean (C3: 355 vs 236)
+    s_thr = unbalanced ? thr : 0u;               // 0: balanced, natural order
+    order[tiles] = unbalanced ? 1u : 0u;
+  }
+  __syncthreads();
+  const uint32_t thr = s_thr;
+  if (thr == 0u) return;
+  const uint32_t thr2 = thr + thr / 3u, thr3 = thr + 2u * (thr / 3u);  // thr = 1.5 x the mean
+  // stable partition into 4 classes: lists >= 2.5 | >= 2 | >= 1.5 times the mean | the rest, tile order kept inside a class
+  uint32_t c3 = 0, c2 = 0, c1 = 0;
+#pragma unroll
+  for (int k = 0; k < PER_MAX; k++) {
+    const int t = t0 + k;
+    if (k < per && t < tiles) {
+      c3 += cnt[k] >= thr3 ? 1u : 0u;
+      c2 += (cnt[k] >= thr2 && cnt[k] < thr3) ? 1u : 0u;
+      c1 += (cnt[k] >= thr && cnt[k] < thr2) ? 1u : 0u;
+    }
+  }
+  const uint32_t i3 = wave_incl_scan(c3), i2 = wave_incl_scan(c2), i1s = wave_incl_scan(c1);
+  if (lane == WAVE - 1) {
+    s_cls[wave][0] = i3;
+    s_cls[wave][1] = i2;
+    s_cls[wave][2] = i1s;
+  }
+  __syncthreads();
+  uint32_t o3 = i3 - c3, o2 = i2 - c2, o1 = i1s - c1, n3 = 0, n2 = 0, n1 = 0;
+  for (int w = 0; w < HB / WAVE; w++) {
+    if (w < wave) {
+      o3 += s_cls[w][0];
+      o2 += s_cls[w][1];
+      o1 += s_cls[w][2];
+    }
+    n3 += s_cls[w][0];
+    n2 += s_cls[w][1];
+    n1 += s_cls[w][2];
+  }
+  o2 += n3;
+  o1 += n3 + n2;
+  // class 0 position = (tile index) - (tiles of higher classes in front of it) + (all tiles of higher classes)
+  uint32_t higher_before = (o3) + (o2 - n3) + (o1 - n3 - n2);
+#pragma unroll
+  for (int k = 0; k < PER_MAX; k++) {
+    const int t = t0 + k;
+    if (k < per && t < tiles) {
+      const uint32_t n_ = cnt[k];
+      uint32_t pos;
+      if (n_ >= thr3) pos = o3++;
+      else if (n_ >= thr2) pos = o2++;
+      else if (n_ >= thr) pos = o1++;
+      else pos = (uint32_t)t - higher_before + (n3 + n2 + n1);
+      if (n_ >= thr) higher_before++;
+      order[pos] = (uint32_t)t;
+    }
   }
 }
 
@@ -733,8 +827,8 @@ bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity) 
 }
 
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, bool scan_fused, const Options &opt,
-                   hipStream_t stream, int debug) {
+                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *dev_status, bool check_prefilter, bool scan_fused,
+                   const Options &opt, hipStream_t stream, int debug) {
   const size_t tiles = (size_t)grid_x * grid_y;
   if (grid_x >= 1024 || grid_y >= 1024) {
     set_error("image larger than 16368 px per side is not supported by the packed tile rect");
@@ -778,12 +872,12 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     GSR_LAUNCH_CHECK(stream, debug);
     if (!device_sized && capacity == 0) {  // nothing to bin (R = 0 read by the host): only the empty ranges and the status
       hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
-                         g.total, cap32, dev_status, 1, check_prefilter ? 1 : 0);
+                         g.total, cap32, dev_status, 1, check_prefilter ? 1 : 0, order);
       GSR_LAUNCH_CHECK(stream, debug);
       return GSR_OK;
     }
     hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
-                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0);
+                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;
@@ -796,7 +890,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
                          b.tile_counts, b.vals_a, cap32, CSTRIDE);
     GSR_LAUNCH_CHECK(stream, debug);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, b.tile_counts, b.tile_cursor, ranges, (int)tiles,
-                       g.total, cap32, dev_status, CSTRIDE, check_prefilter ? 1 : 0);
+                       g.total, cap32, dev_status, CSTRIDE, check_prefilter ? 1 : 0, order);
     GSR_LAUNCH_CHECK(stream, debug);
     if (!device_sized && capacity == 0) return GSR_OK;
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,

@@ -129,8 +129,9 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   __shared__ uint32_t s_id[WAVE + 4];
   __shared__ uint32_t s_slot[DET ? WAVE + 4 : 1];
 
-  const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);
-  const uint32_t tile = item / WPT, part = item % WPT;
+  const bool ordered = tile_order_active(a.order, (uint32_t)(a.grid_x * a.grid_y));
+  const uint32_t item = ordered ? (WPT == 4 ? ordered_item4(blockIdx.x, (uint32_t)(a.grid_x * a.grid_y)) : blockIdx.x) : xcd_remap_b(blockIdx.x, gridDim.x);
+  const uint32_t tile = (ordered ? a.order[item / WPT] : item / WPT), part = item % WPT;
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
@@ -583,8 +584,9 @@ __global__ __launch_bounds__(WAVE) void blend_backward_mfma_kernel(const BlendBw
   __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
   __shared__ uint32_t s_id[WAVE + 4];
 
-  const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);
-  const uint32_t tile = item >> 2, part = item & 3;
+  const bool ordered = tile_order_active(a.order, (uint32_t)(a.grid_x * a.grid_y));
+  const uint32_t item = ordered ? ordered_item4(blockIdx.x, (uint32_t)(a.grid_x * a.grid_y)) : xcd_remap_b(blockIdx.x, gridDim.x);
+  const uint32_t tile = (ordered ? a.order[item >> 2] : item >> 2), part = item & 3;
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
@@ -816,8 +818,9 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
   extern __shared__ __attribute__((aligned(16))) float s_dx[];  // [live channel][c = pixel & 15][q = pixel >> 4]
   static_assert(FX_BASE2 + FX_TRI2 <= WAVE * FX_LROW, "second-hop regions must fit the transposition buffer");
 
-  const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);
-  const uint32_t tile = item / 4, part = item % 4;
+  const bool ordered = tile_order_active(a.order, (uint32_t)(a.grid_x * a.grid_y));
+  const uint32_t item = ordered ? ordered_item4(blockIdx.x, (uint32_t)(a.grid_x * a.grid_y)) : xcd_remap_b(blockIdx.x, gridDim.x);
+  const uint32_t tile = (ordered ? a.order[item / 4] : item / 4), part = item % 4;
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];

@@ -328,7 +328,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   int rc;
   prof_begin(PROF_BINNING, stream);
   if (R_host < 0 || opt.binning_mode == GSR_BINNING_TILE_BUCKET) {
-    rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, dev_status, in.prefiltered != 0,
+    rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, img.order, dev_status, in.prefiltered != 0,
                         scan_fused, opt, stream, in.debug);
     if (rc != GSR_OK) return rc;
   } else {
@@ -347,6 +347,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
     if (rc != GSR_OK) return rc;
     rc = launch_tile_ranges(R, bin.keys_s, img.ranges, tiles, stream);
     if (rc != GSR_OK) return rc;
+    GSR_HIP(hipMemsetAsync(img.order + tiles, 0, sizeof(uint32_t), stream));  // natural tile order
     GSR_LAUNCH_CHECK(stream, in.debug);
   }
   prof_end(PROF_BINNING, stream);
@@ -354,6 +355,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   BlendFwdArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.ranges = img.ranges;
+  fa.order = img.order;
   fa.point_list = bin.vals_s;
   fa.recs = geom.recs;
   fa.W = in.width;
@@ -564,6 +566,7 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
   BlendBwdArgs ba;
   memset(&ba, 0, sizeof(ba));
   ba.ranges = img.ranges;
+  ba.order = img.order;
   ba.point_list = bin.vals_s;
   ba.recs = geom.recs;
   ba.W = width;

@@ -55,6 +55,8 @@ struct ImageState {
   float *final_T;       // [H*W]
   uint32_t *n_contrib;  // [H*W]
   uint2 *ranges;        // [tiles]
+  uint32_t *order;      // [tiles + 1] the order in which the blend kernels visit the tiles (long lists first), [tiles] = 1 if it
+                        // is to be used, 0 = natural order (written by every binning path)
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -116,11 +118,12 @@ inline ImageState image_from_chunk(char *chunk, size_t npix, size_t tiles) {
   carve(chunk, s.final_T, npix);
   carve(chunk, s.n_contrib, npix);
   carve(chunk, s.ranges, tiles);
+  carve(chunk, s.order, tiles + 1);
   return s;
 }
 inline size_t image_bytes(size_t npix, size_t tiles) {
   ImageState s = image_from_chunk(nullptr, npix, tiles);
-  return reinterpret_cast<size_t>(s.ranges + tiles) + 256;
+  return reinterpret_cast<size_t>(s.order + tiles + 1) + 256;
 }
 
 // ---- error plumbing (gsr_api.hip) -------------------------------------------------------------
@@ -190,6 +193,7 @@ inline int radix_passes(int end_bit) { return (end_bit + 7) / 8; }
 int launch_tile_ranges(size_t R, const uint64_t *keys_sorted, uint2 *ranges, size_t tiles, hipStream_t stream);
 
 struct BlendFwdArgs {
+  const uint32_t *order;  // ImageState::order (null: natural order)
   const uint2 *ranges;
   const uint32_t *point_list;
   const SplatRec *recs;
@@ -202,8 +206,21 @@ struct BlendFwdArgs {
   float *out_extra;    // [CE][H][W]
 };
 int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream);
+// is ImageState::order to be used (its flag word behind the last entry)?  Then the work items are NOT remapped to keep
+// neighbouring tiles on one XCD: the long lists at the front of the order must spread over all eight XCDs (hardware assigns
+// workgroup i to XCD i % 8).  With the remap they all landed on XCD 0: 377 instead of 212 us in the render() frame.
+__device__ __forceinline__ bool tile_order_active(const uint32_t *order, uint32_t n_tiles) { return order && order[n_tiles]; }
+// ordered visiting with four waves per tile: workgroup i -> (order slot, quadrant) such that consecutive slots go to different
+// XCDs (i % 8) while the four quadrants of a slot share one (their Gaussians are fetched into one L2, not four)
+__device__ __forceinline__ uint32_t ordered_item4(uint32_t i, uint32_t n_tiles) {
+  const uint32_t full = (n_tiles / 8u) * 32u;  // workgroups of the complete groups of 8 slots x 4 quadrants
+  if (i >= full) return i;                     // the last, partial group: plain (slot = i / 4, quadrant = i % 4)
+  const uint32_t slot = (i / 32u) * 8u + (i % 8u), part = (i / 8u) % 4u;
+  return slot * 4u + part;
+}
 
 struct BlendBwdArgs {
+  const uint32_t *order;  // ImageState::order (null: natural order)
   const uint2 *ranges;
   const uint32_t *point_list;
   const SplatRec *recs;
@@ -258,8 +275,8 @@ int launch_query_recs(int what, int P, const GeomState &g, void *dst, hipStream_
 // capacity = instances the binning buffer holds.  device_sized: the host does not know R; the kernels read it from
 // g.total, write dev_status[0] = R, dev_status[1] = (R > capacity) | 2 * (prefilter violation) and render nothing on overflow.
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *dev_status, bool check_prefilter, bool scan_fused, const Options &opt,
-                   hipStream_t stream, int debug);
+                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *dev_status, bool check_prefilter, bool scan_fused,
+                   const Options &opt, hipStream_t stream, int debug);
 // true if bucket_binning will take its atomics-free histogram path (which can also do the block-sums scan: scan_fused)
 bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity);
 
