@@ -378,7 +378,6 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   // keep the natural order and its L2 locality (flag word 0).
   if (blockIdx.x != gridDim.x - 1) return;
   __shared__ uint32_t s_red[HB / WAVE][2];
-  __shared__ uint32_t s_cls[HB / WAVE][3];
   __shared__ uint32_t s_thr;
   uint32_t busy = 0, mx = 0;
 #pragma unroll
@@ -405,61 +404,43 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
       all += s_wtot[w];  // (the waves' sums of the tile totals, from the scan above)
     }
     const uint32_t mean = b ? all / b : 0u;
-    const uint32_t thr = mean + mean / 2u + 1u;  // "long" = more than 1.5 x the mean list of the busy tiles
     const bool unbalanced = m >= 2u * mean + 1u; // reorder only if some list is more than twice the mean (C3: 355 vs 236)
-    s_thr = unbalanced ? thr : 0u;               // 0: balanced, natural order
+    s_thr = unbalanced ? m : 0u;                 // 0: balanced, natural order
     order[tiles] = unbalanced ? 1u : 0u;
   }
   __syncthreads();
-  const uint32_t thr = s_thr;
-  if (thr == 0u) return;
-  const uint32_t thr2 = thr + thr / 3u, thr3 = thr + 2u * (thr / 3u);  // thr = 1.5 x the mean
-  // stable partition into 4 classes: lists >= 2.5 | >= 2 | >= 1.5 times the mean | the rest, tile order kept inside a class
-  uint32_t c3 = 0, c2 = 0, c1 = 0;
+  const uint32_t mxn = s_thr;  // the longest list, 0: balanced
+  if (mxn == 0u) return;
+  // counting sort of the tiles by list length, longest first: 64 length classes (class of n = ceil-ish of 63 n / max, empty
+  // tiles last), the order inside a class is whatever the LDS atomics give (every tile is rendered by itself: any order of
+  // equals is as good)
+  constexpr int NCLS = 64;
+  __shared__ uint32_t s_ccount[NCLS], s_cbase[NCLS];
+  if ((int)threadIdx.x < NCLS) s_ccount[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t mycls[PER_MAX];
 #pragma unroll
   for (int k = 0; k < PER_MAX; k++) {
     const int t = t0 + k;
+    mycls[k] = 0u;
     if (k < per && t < tiles) {
-      c3 += cnt[k] >= thr3 ? 1u : 0u;
-      c2 += (cnt[k] >= thr2 && cnt[k] < thr3) ? 1u : 0u;
-      c1 += (cnt[k] >= thr && cnt[k] < thr2) ? 1u : 0u;
+      mycls[k] = cnt[k] == 0u ? 0u : 1u + (uint32_t)(((uint64_t)cnt[k] * (NCLS - 2)) / mxn);  // 1 .. NCLS - 1
+      atomicAdd(&s_ccount[mycls[k]], 1u);
     }
-  }
-  const uint32_t i3 = wave_incl_scan(c3), i2 = wave_incl_scan(c2), i1s = wave_incl_scan(c1);
-  if (lane == WAVE - 1) {
-    s_cls[wave][0] = i3;
-    s_cls[wave][1] = i2;
-    s_cls[wave][2] = i1s;
   }
   __syncthreads();
-  uint32_t o3 = i3 - c3, o2 = i2 - c2, o1 = i1s - c1, n3 = 0, n2 = 0, n1 = 0;
-  for (int w = 0; w < HB / WAVE; w++) {
-    if (w < wave) {
-      o3 += s_cls[w][0];
-      o2 += s_cls[w][1];
-      o1 += s_cls[w][2];
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int c = NCLS - 1; c >= 0; c--) {
+      s_cbase[c] = run;
+      run += s_ccount[c];
     }
-    n3 += s_cls[w][0];
-    n2 += s_cls[w][1];
-    n1 += s_cls[w][2];
   }
-  o2 += n3;
-  o1 += n3 + n2;
-  // class 0 position = (tile index) - (tiles of higher classes in front of it) + (all tiles of higher classes)
-  uint32_t higher_before = (o3) + (o2 - n3) + (o1 - n3 - n2);
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < PER_MAX; k++) {
     const int t = t0 + k;
-    if (k < per && t < tiles) {
-      const uint32_t n_ = cnt[k];
-      uint32_t pos;
-      if (n_ >= thr3) pos = o3++;
-      else if (n_ >= thr2) pos = o2++;
-      else if (n_ >= thr) pos = o1++;
-      else pos = (uint32_t)t - higher_before + (n3 + n2 + n1);
-      if (n_ >= thr) higher_before++;
-      order[pos] = (uint32_t)t;
-    }
+    if (k < per && t < tiles) order[atomicAdd(&s_cbase[mycls[k]], 1u)] = (uint32_t)t;
   }
 }
 
