@@ -27,12 +27,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
 // CE > 0: fused multi-feature blend -- CE extra colour channels (a.extra[P][CE]) are composited with the same weights in
 // the same pass (the reference rasterises seven times per frame for them, gaussian_renderer/__init__.py:203-272).
 template <int SLOTS, int CE>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(6))) void blend_forward_kernel(const BlendFwdArgs a) {
+__global__ __launch_bounds__(WAVE) void blend_forward_kernel(const BlendFwdArgs a) {
   constexpr int WPT = 4 / SLOTS;  // waves per tile
-  // channel colours staged at a time: half a batch (the records of the whole batch stay), so that a wave stays at 5.4 KB of
-  // LDS and 6 waves per SIMD fit (at 7.7 KB five did, and the ~5,400 busy waves of a body close-up needed a second round)
-  constexpr int FBW = CE > 0 ? WAVE / 2 : WAVE;
-  __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? FBW * CE : 4];  // survivors' extra channels
+  __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];  // survivors' extra channels
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   // what the cut-off test needs sits in s0 + the first half of s1, what only a blending survivor needs in the second half of s1 +
   // s2: each branch's LDS reads are whole 8- / 16-byte accesses (a 4-byte broadcast read costs as many LDS cycles as an 8-byte one,
@@ -91,7 +88,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(6))) void 
     p1 = src[1];
     p2 = src[2];
   }
-  if (CE == 0 && (int)lane + WAVE < n) id_a = a.point_list[range.x + lane + WAVE];
+  if ((int)lane + WAVE < n) id_a = a.point_list[range.x + lane + WAVE];
   for (int base = 0; base < n; base += WAVE) {
     bool all_done = true;
 #pragma unroll
@@ -101,15 +98,6 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(6))) void 
     // ---- this batch's 64 list entries (already in registers), the next batches' loads, cull against the wave's rectangle,
     // compact the survivors into LDS
     const int idx = base + (int)lane;
-    if constexpr (CE > 0) {  // (no prefetch in the 18-channel variant: its 13 registers would cost the sixth wave per SIMD)
-      if (base > 0 && idx < n) {
-        id_cur = a.point_list[range.x + idx];
-        const float4 *src = reinterpret_cast<const float4 *>(a.recs + id_cur);
-        p0 = src[0];
-        p1 = src[1];
-        p2 = src[2];
-      }
-    }
     const float4 r0 = p0, r1c = p1, r2 = p2;
     const uint32_t id = id_cur;
     (void)id_b;
@@ -122,75 +110,69 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(6))) void 
     }
     const uint64_t kmask = __ballot(keep);
     const int cnt = __builtin_popcountll(kmask);
-    const int slot = __builtin_popcountll(kmask & lt);
     if (keep) {
+      const int slot = __builtin_popcountll(kmask & lt);
       // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
       constexpr float L2E = 1.4426950408889634f;
       s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
       s1[slot] = make_float4((-0.5f * L2E) * r1.x, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(idx + 1)), r1.y);
       s2[slot] = make_float4(r1.w, r2.x, r2.y, r1.z);
-    }
-    for (int h0 = 0; h0 == 0 || h0 < cnt; h0 += FBW) {
       if (CE > 0) {
-        if (keep && slot >= h0 && slot < h0 + FBW) {
-          const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
+        const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
 #pragma unroll
-          for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[(slot - h0) * CE])[q] = xs[q];
-        }
+        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[slot * CE])[q] = xs[q];
       }
-      if (CE == 0 && h0 == 0) {
-        // the next batch's records and the list entries of the batch after it go out AFTER this batch's channel-colour loads
-        // (loads retire in order: waiting for those must not wait for these).  (Prefetching the channel colours of the next
-        // batch as well -- 18 more registers, for survivors or not -- was slower: 221 vs 209 us in the render() frame.)
-        id_cur = id_a;
-        if (idx + WAVE < n) {
-          const float4 *src = reinterpret_cast<const float4 *>(a.recs + id_a);
-          p0 = src[0];
-          p1 = src[1];
-          p2 = src[2];
-        }
-        if (idx + 2 * WAVE < n) id_a = a.point_list[range.x + idx + 2 * WAVE];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-      // ---- blend the survivors
-      const int m = min(FBW, cnt - h0);
-      for (int k = 0; k < m; k++) {
-        const float4 g0 = s0[h0 + k];
-        const float4 g1 = s1[h0 + k];
-        const float4 g2 = s2[h0 + k];
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-          const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
-          const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
-          // cheap necessary condition for alpha >= 1/255:  log2(255*o) + power*log2(e) >= 0  (0.02 safety margin)
-          const bool pre = !(p2 > 0.0f) && ((p2 + g1.y) >= dbias[s]);
-          if (__ballot(pre) != 0ull) {
-            const float alpha = fminf(0.99f, g1.w * __builtin_amdgcn_exp2f(p2));
-            const bool hit = pre && !(alpha < 1.0f / 255.0f);
-            const float test_T = T[s] * (1.0f - alpha);
-            const bool stop = hit && test_T < 0.0001f;
-            const bool blend = hit && !stop;
-            dbias[s] = stop ? 1e30f : dbias[s];
-            const float w = blend ? alpha * T[s] : 0.0f;
-            C0[s] += g2.x * w;
-            C1[s] += g2.y * w;
-            C2[s] += g2.z * w;
-            Dp[s] += g2.w * w;
-            Wt[s] += w;
-            if (CE > 0) {
-#pragma unroll
-              for (int c = 0; c < CE; c++) X[s][c] += s_x[k * CE + c] * w;
-            }
-            T[s] = blend ? test_T : T[s];
-            last[s] = blend ? __float_as_uint(g1.z) : last[s];
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // keep the next LDS writes behind these reads
     }
+    // the next batch's records and the list entries of the batch after it go out AFTER this batch's channel-colour loads
+    // (loads retire in order: waiting for those must not wait for these).  Measured in the render() frame and dropped:
+    // prefetching the channel colours of the next batch as well (18 more registers: 221 vs 209 us); staging the channel
+    // colours half a batch at a time to fit a sixth wave per SIMD (amdgpu_waves_per_eu(6), no prefetch: 163 vs 153 us).
+    id_cur = id_a;
+    if (idx + WAVE < n) {
+      const float4 *src = reinterpret_cast<const float4 *>(a.recs + id_a);
+      p0 = src[0];
+      p1 = src[1];
+      p2 = src[2];
+    }
+    if (idx + 2 * WAVE < n) id_a = a.point_list[range.x + idx + 2 * WAVE];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- blend the survivors
+    for (int k = 0; k < cnt; k++) {
+      const float4 g0 = s0[k];
+      const float4 g1 = s1[k];
+      const float4 g2 = s2[k];
+#pragma unroll
+      for (int s = 0; s < SLOTS; s++) {
+        const float dx = g0.x - pxf[s], dy = g0.y - pyf[s];
+        const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
+        // cheap necessary condition for alpha >= 1/255:  log2(255*o) + power*log2(e) >= 0  (0.02 safety margin)
+        const bool pre = !(p2 > 0.0f) && ((p2 + g1.y) >= dbias[s]);
+        if (__ballot(pre) != 0ull) {
+          const float alpha = fminf(0.99f, g1.w * __builtin_amdgcn_exp2f(p2));
+          const bool hit = pre && !(alpha < 1.0f / 255.0f);
+          const float test_T = T[s] * (1.0f - alpha);
+          const bool stop = hit && test_T < 0.0001f;
+          const bool blend = hit && !stop;
+          dbias[s] = stop ? 1e30f : dbias[s];
+          const float w = blend ? alpha * T[s] : 0.0f;
+          C0[s] += g2.x * w;
+          C1[s] += g2.y * w;
+          C2[s] += g2.z * w;
+          Dp[s] += g2.w * w;
+          Wt[s] += w;
+          if (CE > 0) {
+#pragma unroll
+            for (int c = 0; c < CE; c++) X[s][c] += s_x[k * CE + c] * w;
+          }
+          T[s] = blend ? test_T : T[s];
+          last[s] = blend ? __float_as_uint(g1.z) : last[s];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // keep the next batch's LDS writes behind this batch's reads
   }
 
   const size_t plane = (size_t)a.H * a.W;
