@@ -70,6 +70,9 @@ int gsr_get_binning_mode(void);
  *   "bucket_hist" in {0, 1}: tile-bucket counting without global atomics (per-workgroup LDS histograms + a dense prefix table,
  *       default) or with one returning global atomic per instance (also taken for tile grids beyond 8192 tiles);
  *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the atomic variant;
+ *   "tile_order" in {0, 1}: the order in which the blend kernels visit the tiles (tile-bucket back-end, histogram path): 1 =
+ *       longest list first, dealt round-robin to the XCDs (default), 0 = the natural order (a contiguous band of tile rows per
+ *       XCD); results do not depend on it;
  *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above);
  *   "deterministic" in {0, 1}: the backward reduces its per-(Gaussian, tile-quadrant) partial sums in a fixed order instead of
  *       with float atomics: run-to-run bit-identical gradients (for tests; costs a 256-byte slot per instance quadrant).

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(PW *WAVE) void bucket_hist_prefix_kernel(uint32_t *
 __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, const uint32_t *wg_start, int tiles,
                                                                 const uint32_t *totals, const uint32_t *table, const uint32_t *rank,
                                                                 const uint32_t *gids, uint64_t *bucket, uint32_t capacity,
-                                                                uint2 *ranges, uint32_t *status, int check_prefilter, uint32_t *order) {
+                                                                uint2 *ranges, uint32_t *status, int check_prefilter, uint32_t *order, int order_mode) {
   constexpr int PER_MAX = (HIST_MAX_TILES + HB - 1) / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
@@ -370,12 +370,14 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     const uint32_t dbits = __float_as_uint(g.recs[gid].depth);
     bucket[s_base[r >> 16] + (r & 0xFFFFu)] = ((uint64_t)dbits << 32) | (uint64_t)gid;
   }
-  // ---- visiting order of the tiles for the blend kernels (the last workgroup, which has the least scatter work left to hide
-  // it behind... any single workgroup will do): tiles whose list is much longer than the average go FIRST.  A wave walks its
-  // list serially (a dependent chain per survivor), so the kernel cannot end before its longest list has been walked from
-  // wherever that wave STARTED: in a close-up of a body (1,480 busy tiles, lists up to 3x the mean) the long lists of the
-  // lower image rows started after the first round of waves had retired.  Balanced scenes (C3: no list above 2x the mean)
-  // keep the natural order and its L2 locality (flag word 0).
+  // ---- visiting order of the tiles for the blend kernels (built by the last workgroup): the tiles with the longest lists go
+  // FIRST, dealt round-robin to the eight XCDs (tile_order_active / ordered_item4 in gsr_common.h).  A wave walks its list
+  // serially, so a blend kernel cannot end before its longest list has been walked from wherever that wave STARTED, and the
+  // natural order with a contiguous band of tile rows per XCD leaves whole XCDs short of work when the scene is not uniform.
+  // Measured: close-up of a body (1,480 busy tiles, lists up to 3x the mean) blend forward 212 -> 153 us, backward 419 -> 284;
+  // C3 (uniform cloud, lists 150..355) forward 114 -> 103, backward 230 -> 211: the balance is worth more than keeping
+  // neighbouring tiles on one L2.  (Longest first INSIDE each XCD's band of tile rows, to keep that locality: 0.440 vs
+  // 0.415 ms per C3 step; the long lists merely moved to the front of the contiguous mapping: all on XCD 0, 377 vs 212 us.)
   if (blockIdx.x != gridDim.x - 1) return;
   __shared__ uint32_t s_red[HB / WAVE][2];
   __shared__ uint32_t s_thr;
@@ -403,17 +405,17 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
       m = max(m, s_red[w][1]);
       all += s_wtot[w];  // (the waves' sums of the tile totals, from the scan above)
     }
-    const uint32_t mean = b ? all / b : 0u;
-    const bool unbalanced = m >= 2u * mean + 1u; // reorder only if some list is more than twice the mean (C3: 355 vs 236)
-    s_thr = unbalanced ? m : 0u;                 // 0: balanced, natural order
-    order[tiles] = unbalanced ? 1u : 0u;
+    (void)b;
+    (void)all;
+    s_thr = order_mode == 0 ? 0u : m;  // Options::tile_order: 0 natural order, 1 longest lists first (default)
+    order[tiles] = s_thr ? 1u : 0u;
   }
   __syncthreads();
-  const uint32_t mxn = s_thr;  // the longest list, 0: balanced
+  const uint32_t mxn = s_thr;  // the longest list, 0: natural order (or nothing to render)
   if (mxn == 0u) return;
-  // counting sort of the tiles by list length, longest first: 64 length classes (class of n = ceil-ish of 63 n / max, empty
-  // tiles last), the order inside a class is whatever the LDS atomics give (every tile is rendered by itself: any order of
-  // equals is as good)
+  // counting sort of the tiles by list length, longest first: 64 length classes (class of n = 1 + 62 n / max, empty tiles last),
+  // the order inside a class is whatever the LDS atomics give (every tile is rendered by itself: any order of equals is as
+  // good)
   constexpr int NCLS = 64;
   __shared__ uint32_t s_ccount[NCLS], s_cbase[NCLS];
   if ((int)threadIdx.x < NCLS) s_ccount[threadIdx.x] = 0u;
@@ -858,7 +860,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
       return GSR_OK;
     }
     hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
-                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order);
+                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;

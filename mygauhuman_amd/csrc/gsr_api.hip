@@ -77,6 +77,9 @@ static int set_option(Options &o, const char *key, int v) {
   } else if (!strcmp(key, "bucket_hist")) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.bucket_hist = v;
+  } else if (!strcmp(key, "tile_order")) {
+    if (v != 0 && v != 1) return bad("0 (natural order) or 1 (longest lists first)");
+    o.tile_order = v;
   } else if (!strcmp(key, "tile_cull")) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.tile_cull = v;

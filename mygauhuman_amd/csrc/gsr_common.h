@@ -156,6 +156,7 @@ void prof_end(int stage, hipStream_t stream);
 struct Options {
   int binning_mode = GSR_BINNING_TILE_BUCKET;
   int tile_cull = 1;         // exact ellipse-vs-tile culling of instances in the tile-bucket back-end
+  int tile_order = 1;        // blend kernels visit the tiles longest list first, spread over the XCDs (1, default) or in the natural order (0)
   int bucket_hist = 1;       // atomics-free counting of the tile-bucket back-end (LDS histograms per workgroup); 0 = global atomics
   int bucket_cstride = 4;    // counters per 64-byte line = 16 / stride (interleaved A/B at C3, us of binning: 1: 112, 2: 106, 4: 100, 16: 126)
   int blend_fwd_waves = 4;   // waves that cooperate on one 16x16 tile

@@ -352,3 +352,41 @@ def test_deterministic_backward_and_per_stream_knobs(oracle):
     finally:
         for st in streams:
             _lib.clear_stream_tuning(st)
+
+
+@pytest.mark.parametrize("P,W,H,scale", [(9000, 208, 144, 0.03), (20000, 400, 304, 0.01)])
+def test_tile_visiting_order_does_not_change_results(P, W, H, scale):
+    """Options::tile_order (0 natural, 1 longest lists first): the blend kernels only VISIT the tiles in
+    another order (and on other XCDs); images, per-pixel state and -- with the fixed-order reduction -- gradients keep their bits."""
+    from mygauhuman_amd import _lib
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    cam, g = util.make_scene(P, W, H, 13, 3, scale, 0.02)
+    d = util.to_dev
+    bg = d(np.array([0.3, 0.2, 0.1], np.float32))
+    e = torch.empty(0)
+    T = {k: d(g[k]) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+    cm = {k: d(cam[k]) for k in ("viewmatrix", "projmatrix", "campos")}
+    rng = np.random.default_rng(5)
+    dc, dd, da = (d(rng.normal(0, 1, s).astype(np.float32)) for s in ((3, H, W), (1, H, W), (1, H, W)))
+    res = {}
+    _lib.set_tuning("deterministic", 1)
+    try:
+        for mode in (0, 1):
+            _lib.set_tuning("tile_order", mode)
+            o = _C.rasterize_gaussians(bg, T["means3D"], e, T["opacities"], T["scales"], T["rotations"], 1.0, e, cm["viewmatrix"],
+                                       cm["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, T["shs"], 3, cm["campos"], False, False)
+            gr = _C.rasterize_gaussians_backward(bg, T["means3D"], o[4], e, T["scales"], T["rotations"], 1.0, e, cm["viewmatrix"],
+                                                 cm["projmatrix"], cam["tanfovx"], cam["tanfovy"], dc, dd, da, T["shs"], 3,
+                                                 cm["campos"], o[5], o[0], o[6], o[7], o[3], False)
+            res[mode] = ([o[1], o[2], o[3], _C.query_state("N_CONTRIB", P, o[0], W, H, o[5], o[6], o[7]),
+                          _C.query_state("FINAL_T", P, o[0], W, H, o[5], o[6], o[7])], list(gr))
+    finally:
+        _lib.set_tuning("deterministic", 0)
+        _lib.set_tuning("tile_order", 1)
+    for mode in (1,):
+        for a, b in zip(res[0][0], res[mode][0]):
+            assert torch.equal(a, b)
+        for a, b in zip(res[0][1], res[mode][1]):
+            assert torch.equal(a, b)
+    with pytest.raises(_lib.GsrError):
+        _lib.set_tuning("tile_order", 2)
