@@ -529,6 +529,8 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
                               const float *const *dL_dout_extra, float *dL_dextra, int sh_dtype, gsr_stream_t stream_) {
   // alphas: unused by the reference kernel (CR/backward.cu:410); read by the fused alpha-mask loss only
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int flags = debug;  // bit 0: debug mode, GSR_BWD_ROWS_ZEROED
+  debug &= 1;
   if (P < 0 || R < 0 || width <= 0 || height <= 0) {
     set_error("gsr_rasterize_backward: bad sizes");
     return GSR_EINVAL;
@@ -563,7 +565,7 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
     // (a test mode: plain hipMalloc / hipFree around the call, no stream-ordered pool involved)
     GSR_HIP(hipMalloc(reinterpret_cast<void **>(&det_rows), det_bytes));
     GSR_HIP(hipMemsetAsync(det_rows, 0, det_bytes, stream));
-  } else {
+  } else if (!(flags & GSR_BWD_ROWS_ZEROED)) {
     GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * grow * sizeof(float), stream));
   }
   BlendBwdArgs ba;
@@ -636,6 +638,7 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
   pb.focal_x = width / (2.0f * tan_fovx);
   pb.grad_rows = geom.grad_rows;
   pb.grow = grow;
+  pb.clear_rows = (flags & GSR_BWD_ROWS_ZEROED) ? 1 : 0;
   pb.CE = n_extra;
   pb.sh_half = sh_dtype == GSR_SH_F16 ? 1 : 0;
   pb.dL_dextra = dL_dextra;

@@ -260,8 +260,9 @@ struct PreprocessBwdArgs {
   const float *view, *proj, *campos;
   int W, H;
   float tan_fovx, tan_fovy, focal_x, focal_y;
-  const float *grad_rows;
+  float *grad_rows;
   int grow;          // row stride of grad_rows (GROW or GROWX)
+  int clear_rows;    // 1: leave the rows zero again once they are consumed (GSR_BWD_ROWS_ZEROED: no memset in the next backward)
   int CE;            // extra feature channels (their gradients sit in row columns 9 .. 9+CE-1)
   float *dL_dextra;  // [P][CE]
   const SplatRec *recs;

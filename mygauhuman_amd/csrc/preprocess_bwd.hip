@@ -86,8 +86,14 @@ __device__ __forceinline__ void preprocess_backward_one(const PreprocessBwdArgs 
       for (int k = 0; k < a.M * 3; k++) dsh_out[k] = 0.f;
     return;  // (the extra-channel gradients of the whole workgroup are copied cooperatively by the kernel)
   }
-  const float4 *row = reinterpret_cast<const float4 *>(a.grad_rows + (size_t)i * a.grow);
+  float4 *row = reinterpret_cast<float4 *>(a.grad_rows + (size_t)i * a.grow);
   const float4 m0 = row[0], m1 = row[1], m2 = row[2];
+  if (a.clear_rows) {  // columns 0..11 (with feature channels the workgroup has cleared the columns behind them, after its copy)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    row[0] = z;
+    row[1] = z;
+    row[2] = z;
+  }
   // moments -> blend gradients (CR/backward.cu:567-584), conic / opacity from the forward's splat record
   const float4 rec0 = reinterpret_cast<const float4 *>(a.recs + i)[0];
   const float4 rec1 = reinterpret_cast<const float4 *>(a.recs + i)[1];
@@ -259,6 +265,15 @@ __global__ __launch_bounds__(BWD_BLOCK) void preprocess_backward_kernel(const Pr
     for (int e = threadIdx.x; e < nrows * a.CE; e += BWD_BLOCK) {
       const int r = e / a.CE, c = e - r * a.CE;
       dst[e] = src[(size_t)r * a.grow + c];
+    }
+    if (a.clear_rows) {
+      // the channel columns are consumed: clear them (columns 12.. of every row; 0..11 are cleared by the row's own thread below)
+      __syncthreads();
+      float *rows = a.grad_rows + (size_t)first * a.grow;
+      for (int e = threadIdx.x; e < nrows * (a.grow - 12); e += BWD_BLOCK) {
+        const int r = e / (a.grow - 12), c = e - r * (a.grow - 12);
+        rows[(size_t)r * a.grow + 12 + c] = 0.f;
+      }
     }
   }
   if (STAGE_SH) {

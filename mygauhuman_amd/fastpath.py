@@ -11,13 +11,17 @@ import torch
 
 from ._lib import SH_F16, SH_F32, check, lib
 
+ROWS_ZEROED = 2  # GSR_BWD_ROWS_ZEROED (include/gsr.h)
+
 
 class RasterSession:
     def __init__(self, P, W, H, M, device, capacity, with_backward=True):
         self.P, self.W, self.H, self.M, self.device = int(P), int(W), int(H), int(M), torch.device(device)
         self.capacity = int(capacity)
         dev, u8, f32 = self.device, torch.uint8, torch.float32
-        self.geom = torch.empty(lib.gsr_geometry_bytes(self.P), dtype=u8, device=dev)
+        # zero-filled once: the backward calls of this session carry GSR_BWD_ROWS_ZEROED (the gradient rows inside this buffer
+        # are cleared by the backward that consumed them, no memset per frame)
+        self.geom = torch.zeros(lib.gsr_geometry_bytes(self.P), dtype=u8, device=dev)
         self.img = torch.empty(lib.gsr_image_bytes(self.W, self.H), dtype=u8, device=dev)
         self.bin = torch.empty(lib.gsr_binning_bytes(self.capacity, self.W, self.H), dtype=u8, device=dev)
         self.color = torch.empty((3, self.H, self.W), dtype=f32, device=dev)
@@ -89,7 +93,7 @@ class RasterSession:
             self.geom.data_ptr(), self.bin.data_ptr(), self.img.data_ptr(), dL_dcolor.data_ptr(), dL_ddepth.data_ptr(),
             dL_dalpha.data_ptr(), self.dL_dmean2D.data_ptr(), self.dL_dconic.data_ptr(), out["opacity"].data_ptr(),
             self.dL_dcolors.data_ptr(), out["means3D"].data_ptr(), self.dL_dcov3D.data_ptr(), out["sh"].data_ptr(),
-            out["scales"].data_ptr(), out["rotations"].data_ptr(), 0, None, 0, None, None, sh_dtype, self._stream()),
+            out["scales"].data_ptr(), out["rotations"].data_ptr(), ROWS_ZEROED, None, 0, None, None, sh_dtype, self._stream()),
             "gsr_rasterize_backward")
 
     def backward_alpha_mask_loss(self, params, cam, bg, sh_degree, gt, mask, lambda_alpha, out, scale_modifier=1.0):
@@ -106,7 +110,7 @@ class RasterSession:
             self.geom.data_ptr(), self.bin.data_ptr(), self.img.data_ptr(), self.color.data_ptr(), gt.data_ptr(), mask.data_ptr(),
             float(lambda_alpha), self.dL_dmean2D.data_ptr(), self.dL_dconic.data_ptr(), out["opacity"].data_ptr(),
             self.dL_dcolors.data_ptr(), out["means3D"].data_ptr(), self.dL_dcov3D.data_ptr(), out["sh"].data_ptr(),
-            out["scales"].data_ptr(), out["rotations"].data_ptr(), 0, sh_dtype, self._stream()),
+            out["scales"].data_ptr(), out["rotations"].data_ptr(), ROWS_ZEROED, sh_dtype, self._stream()),
             "gsr_rasterize_backward_alpha_mask_loss")
 
     # `status` may be a device tensor (default) or a pinned host tensor that the kernels write directly (ViewParallelStep)
