@@ -27,7 +27,10 @@ import os
 import sys
 import time
 
-import numpy as np
+# read by the HIP runtime when it starts (hipGraph replays, mygauhuman_amd/graph.py): before anything imports torch
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -161,15 +161,15 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
  * With extra_features == NULL / n_extra == 0 and GSR_SH_F32 the _ex entry points are
  * identical to the plain ones. */
 #define GSR_SH_F32 0 /* shs: float32 [P][M][3] */
-#define GSR_SH_F16 1 /* Flag for the `debug` argument of the backward entry points (bit 0 = the reference's debug mode: synchronise and check after
+#define GSR_SH_F16 1 /* shs: IEEE half [P][16][3] (extension: fp16 SH storage, BASELINE configs[4]); M must be 16, the array
+                      * 16-byte aligned; coefficients are widened exactly on load, dL_dsh stays float32 */
+/* Flag for the `debug` argument of the backward entry points (bit 0 = the reference's debug mode: synchronise and check after
  * every kernel).  GSR_BWD_ROWS_ZEROED: the caller guarantees that the gradient accumulation rows inside geom_buffer are all zero
  * on entry -- true for a geometry buffer that was zero-filled once and has since only been used by backward calls carrying this
  * flag -- and the call leaves them zero again (the backward preprocess clears every row it consumes): no 64-byte-per-Gaussian
  * memset per backward.  Without the flag the rows are zeroed by the call, as before. */
 #define GSR_BWD_ROWS_ZEROED 2
 
-/* shs: IEEE half [P][16][3] (extension: fp16 SH storage, BASELINE configs[4]); M must be 16, the array
-                      * 16-byte aligned; coefficients are widened exactly on load, dL_dsh stays float32 */
 int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
                              gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,
                              int height, const float *means3D, const float *shs, const float *colors_precomp,

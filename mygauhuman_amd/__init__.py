@@ -18,11 +18,19 @@ import sys
 # a graph recorded over this library and torch allocations replays WRONG results once other GPU work has run between two
 # replays (measured on MI355X: profiles/r2_graph_packet_capture.txt; every replay is right with the feature off, at the same
 # replay time).  The flag is read when the HIP runtime initialises, so it has to be in the environment before the first HIP
-# call of the process; GRAPH_REPLAY_SAFE records whether that was still possible when this package was imported.
+# call of the process -- and Python cannot tell when that was: torch.cuda.is_initialized() only tracks torch's own lazy
+# initialisation, while torch.cuda.is_available() / device_count() may already have started the runtime.  So:
+#   * bench.py, the rank launcher and tests/conftest.py export the variable before torch is imported;
+#   * importing this package sets it if nobody has (the only way a plain `import mygauhuman_amd` at the top of a script helps);
+#   * GRAPH_REPLAY_SAFE = False only records the one case that is CERTAINLY too late (torch had initialised HIP before the
+#     import and the variable was not there); True is necessary, not sufficient;
+#   * mygauhuman_amd.graph.GraphedFrame therefore verifies every captured graph once (replay, unrelated eager GPU work, replay,
+#     compare with the eager step) and raises on a mismatch instead of trusting any of the above.
 _torch = sys.modules.get("torch")
-_hip_already_up = bool(_torch is not None and _torch.cuda.is_initialized())
+_hip_certainly_up = bool(_torch is not None and _torch.cuda.is_initialized())
+_flag_was_set = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-GRAPH_REPLAY_SAFE = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and not _hip_already_up
+GRAPH_REPLAY_SAFE = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and (_flag_was_set or not _hip_certainly_up)
 
 __version__ = "0.1.0"
 

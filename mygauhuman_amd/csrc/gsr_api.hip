@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -46,15 +47,43 @@ static uint32_t higher_msb(uint32_t n) {
   return msb;
 }
 
-// ---- options: process defaults + per-stream overrides, resolved once per call (gsr_common.h: Options) ----------------
-static std::mutex g_opt_mutex;
-static Options g_default_opt;
-static std::unordered_map<hipStream_t, Options> g_stream_opt;
+// ---- process-wide host state ------------------------------------------------------------------------------------------
+// Everything mutable the API layer keeps between calls lives in ONE object that is created on first use and never destroyed:
+// threads the library does not own (autograd's backward thread, a data-loader thread) may still be inside a call while the main
+// thread runs static destructors at exit, and a destroyed mutex / map under them is undefined behaviour.  Every member is
+// guarded by the mutex next to it; nothing here is touched below the API layer.
+struct ProfRec {
+  int stage;
+  hipStream_t stream;
+  hipEvent_t e0, e1;
+};
+struct ApiState {
+  // options: process defaults + per-stream overrides, resolved once per call (gsr_common.h: Options)
+  std::mutex opt_mutex;
+  Options default_opt;
+  std::unordered_map<hipStream_t, Options> stream_opt;
+  // per-stage event timing: the autograd backward thread and the main thread both record stages
+  std::mutex prof_mutex;
+  std::atomic<unsigned> prof_mask{0};   // read without the mutex on the fast path (profiling off = two relaxed loads per stage)
+  std::vector<ProfRec> prof_recs;                                 // recorded pairs awaiting collection
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;       // recycled events
+  double prof_ms[PROF_NSTAGES] = {0, 0, 0, 0, 0, 0};
+  long prof_n[PROF_NSTAGES] = {0, 0, 0, 0, 0, 0};
+  // pinned 64-byte slots for the one device->host read of a blocking forward: as many as there are calls in flight at once
+  // (one per calling thread at most), recycled -- not one per thread that ever called
+  std::mutex pin_mutex;
+  std::vector<uint32_t *> pin_free;
+};
+static ApiState &S() {
+  static ApiState *s = new ApiState();  // intentionally leaked, see above
+  return *s;
+}
 
 Options options_for(hipStream_t stream) {
-  std::lock_guard<std::mutex> lock(g_opt_mutex);
-  auto it = g_stream_opt.find(stream);
-  return it == g_stream_opt.end() ? g_default_opt : it->second;
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.opt_mutex);
+  auto it = st.stream_opt.find(stream);
+  return it == st.stream_opt.end() ? st.default_opt : it->second;
 }
 
 static int set_option(Options &o, const char *key, int v) {
@@ -99,61 +128,77 @@ static int set_option(Options &o, const char *key, int v) {
 // pinned host words for the one device->host read of a forward call: num_rendered (CR/rasterizer_impl.cu:283) and the
 // "filtered although prefiltered" flag word next to it
 static int readback_u32x2(const uint32_t *dev, uint32_t *out, hipStream_t stream) {
-  static thread_local uint32_t *pinned = nullptr;
+  ApiState &st = S();
+  uint32_t *pinned = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(st.pin_mutex);
+    if (!st.pin_free.empty()) {
+      pinned = st.pin_free.back();
+      st.pin_free.pop_back();
+    }
+  }
   if (!pinned) GSR_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 64, hipHostMallocDefault));
-  GSR_HIP(hipMemcpyAsync(pinned, dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  GSR_HIP(hipStreamSynchronize(stream));
+  hipError_t e = hipMemcpyAsync(pinned, dev, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
   out[0] = pinned[0];
   out[1] = pinned[1];
+  {
+    std::lock_guard<std::mutex> lock(st.pin_mutex);
+    st.pin_free.push_back(pinned);
+  }
+  GSR_HIP(e);
   return GSR_OK;
 }
 
 // ---- per-stage event timing --------------------------------------------------------------------
-struct ProfRec {
-  int stage;
-  hipEvent_t e0, e1;
-};
-static std::mutex g_prof_mutex;  // the autograd backward thread and the main thread both record stages
-static unsigned g_prof_mask = 0;
-static std::vector<ProfRec> g_prof_recs;           // recorded pairs awaiting collection
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;  // recycled events
-static double g_prof_ms[PROF_NSTAGES];
-static long g_prof_n[PROF_NSTAGES];
-
 void prof_begin(int stage, hipStream_t stream) {
-  if (!(g_prof_mask & (1u << stage))) return;
-  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  ApiState &st = S();
+  if (!(st.prof_mask.load(std::memory_order_relaxed) & (1u << stage))) return;
+  std::lock_guard<std::mutex> lock(st.prof_mutex);
   ProfRec r;
   r.stage = stage;
-  if (!g_prof_pool.empty()) {
-    r.e0 = g_prof_pool.back().first;
-    r.e1 = g_prof_pool.back().second;
-    g_prof_pool.pop_back();
+  r.stream = stream;
+  if (!st.prof_pool.empty()) {
+    r.e0 = st.prof_pool.back().first;
+    r.e1 = st.prof_pool.back().second;
+    st.prof_pool.pop_back();
   } else {
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    if (hipEventCreate(&r.e0) != hipSuccess) return;
+    if (hipEventCreate(&r.e1) != hipSuccess) {
+      (void)hipEventDestroy(r.e0);
+      return;
+    }
   }
   (void)hipEventRecord(r.e0, stream);
-  g_prof_recs.push_back(r);
+  st.prof_recs.push_back(r);
 }
 void prof_end(int stage, hipStream_t stream) {
-  if (!(g_prof_mask & (1u << stage))) return;
-  std::lock_guard<std::mutex> lock(g_prof_mutex);
-  for (size_t i = g_prof_recs.size(); i-- > 0;)
-    if (g_prof_recs[i].stage == stage) {
-      (void)hipEventRecord(g_prof_recs[i].e1, stream);
+  ApiState &st = S();
+  if (!(st.prof_mask.load(std::memory_order_relaxed) & (1u << stage))) return;
+  std::lock_guard<std::mutex> lock(st.prof_mutex);
+  for (size_t i = st.prof_recs.size(); i-- > 0;)  // the newest open record of this stage ON THIS STREAM (threads use their own streams)
+    if (st.prof_recs[i].stage == stage && st.prof_recs[i].stream == stream) {
+      (void)hipEventRecord(st.prof_recs[i].e1, stream);
       return;
     }
 }
-static void prof_collect() {  // caller holds g_prof_mutex
-  for (auto &r : g_prof_recs) {
+static void prof_collect(ApiState &st) {  // caller holds prof_mutex
+  for (auto &r : st.prof_recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
-      g_prof_ms[r.stage] += ms;
-      g_prof_n[r.stage] += 1;
+      st.prof_ms[r.stage] += ms;
+      st.prof_n[r.stage] += 1;
     }
-    g_prof_pool.emplace_back(r.e0, r.e1);
+    st.prof_pool.emplace_back(r.e0, r.e1);
   }
-  g_prof_recs.clear();
+  st.prof_recs.clear();
+}
+static void prof_release_events(ApiState &st) {  // caller holds prof_mutex; profiling has been switched off
+  for (auto &pr : st.prof_pool) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  st.prof_pool.clear();
 }
 
 }  // namespace gsr
@@ -167,41 +212,57 @@ const char *gsr_target_arch(void) { return "gfx950"; }
 const char *gsr_last_error(void) { return g_error.c_str(); }
 
 int gsr_set_tuning(const char *key, int value) {
-  if (!key) return GSR_EINVAL;
-  std::lock_guard<std::mutex> lock(g_opt_mutex);
-  return set_option(g_default_opt, key, value);
+  if (!key) {
+    set_error("gsr_set_tuning: null key");
+    return GSR_EINVAL;
+  }
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.opt_mutex);
+  return set_option(st.default_opt, key, value);
 }
 int gsr_set_stream_tuning(gsr_stream_t stream_, const char *key, int value) {
-  if (!key) return GSR_EINVAL;
+  if (!key) {
+    set_error("gsr_set_stream_tuning: null key");
+    return GSR_EINVAL;
+  }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  std::lock_guard<std::mutex> lock(g_opt_mutex);
-  auto it = g_stream_opt.find(stream);
-  if (it == g_stream_opt.end()) it = g_stream_opt.emplace(stream, g_default_opt).first;  // starts as a copy of the defaults
-  return set_option(it->second, key, value);
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.opt_mutex);
+  auto it = st.stream_opt.find(stream);
+  if (it != st.stream_opt.end()) return set_option(it->second, key, value);
+  Options o = st.default_opt;  // starts as a copy of the defaults; a rejected value does not create an entry
+  int rc = set_option(o, key, value);
+  if (rc == GSR_OK) st.stream_opt.emplace(stream, o);
+  return rc;
 }
 int gsr_clear_stream_tuning(gsr_stream_t stream_) {
-  std::lock_guard<std::mutex> lock(g_opt_mutex);
-  g_stream_opt.erase(reinterpret_cast<hipStream_t>(stream_));
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.opt_mutex);
+  st.stream_opt.erase(reinterpret_cast<hipStream_t>(stream_));
   return GSR_OK;
 }
 int gsr_set_binning_mode(int mode) { return gsr_set_tuning("binning_mode", mode); }
 int gsr_get_binning_mode(void) {
-  std::lock_guard<std::mutex> lock(g_opt_mutex);
-  return g_default_opt.binning_mode;
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.opt_mutex);
+  return st.default_opt.binning_mode;
 }
 
 int gsr_profile_enable(unsigned stage_mask) {
-  std::lock_guard<std::mutex> lock(g_prof_mutex);
-  prof_collect();
-  g_prof_mask = stage_mask & ((1u << PROF_NSTAGES) - 1);
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.prof_mutex);
+  prof_collect(st);
+  st.prof_mask = stage_mask & ((1u << PROF_NSTAGES) - 1);
+  if (!stage_mask) prof_release_events(st);
   return GSR_OK;
 }
 int gsr_profile_reset(void) {
-  std::lock_guard<std::mutex> lock(g_prof_mutex);
-  prof_collect();
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.prof_mutex);
+  prof_collect(st);
   for (int i = 0; i < PROF_NSTAGES; i++) {
-    g_prof_ms[i] = 0.0;
-    g_prof_n[i] = 0;
+    st.prof_ms[i] = 0.0;
+    st.prof_n[i] = 0;
   }
   return GSR_OK;
 }
@@ -210,10 +271,11 @@ int gsr_profile_read(int stage, double *total_ms, long *launches) {
     set_error("gsr_profile_read: bad arguments");
     return GSR_EINVAL;
   }
-  std::lock_guard<std::mutex> lock(g_prof_mutex);
-  prof_collect();
-  *total_ms = g_prof_ms[stage];
-  *launches = g_prof_n[stage];
+  ApiState &st = S();
+  std::lock_guard<std::mutex> lock(st.prof_mutex);
+  prof_collect(st);
+  *total_ms = st.prof_ms[stage];
+  *launches = st.prof_n[stage];
   return GSR_OK;
 }
 

@@ -60,12 +60,15 @@ struct ImageState {
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// Bump allocation at 256-byte alignment (CR/rasterizer_impl.h:21-27 `obtain`).  Works on an integer address so that the same
+// code can size a buffer from address 0 (the *_bytes functions) without doing pointer arithmetic on a null pointer.
 template <typename T>
-inline void carve(char *&p, T *&out, size_t count) {
-  p = reinterpret_cast<char *>(align_up(reinterpret_cast<size_t>(p), 256));
+inline void carve(uintptr_t &p, T *&out, size_t count) {
+  p = align_up(p, 256);
   out = reinterpret_cast<T *>(p);
   p += count * sizeof(T);
 }
+inline uintptr_t carve_begin(const void *chunk) { return reinterpret_cast<uintptr_t>(chunk); }
 
 inline int pre_blocks(int P) { return (P + PRE_BLOCK - 1) / PRE_BLOCK; }
 constexpr int SORT_ITEMS = 16;                        // keys per thread in the radix passes
@@ -74,8 +77,9 @@ constexpr int SORT_TILE = SORT_ITEMS * SORT_BLOCK;    // keys per block
 inline size_t sort_blocks(size_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 inline size_t sort_hist_words(size_t n) { return 256 * (sort_blocks(n) ? sort_blocks(n) : 1) + 256; }
 
-inline GeomState geom_from_chunk(char *chunk, size_t P) {
+inline GeomState geom_from_chunk(char *chunk_, size_t P, size_t *end = nullptr) {
   GeomState g;
+  uintptr_t chunk = carve_begin(chunk_);
   size_t nb = (size_t)pre_blocks((int)P);
   carve(chunk, g.recs, P);
   carve(chunk, g.cov3D, P * 6);
@@ -88,14 +92,17 @@ inline GeomState geom_from_chunk(char *chunk, size_t P) {
   carve(chunk, g.block_prefix, nb);
   carve(chunk, g.total, 4);
   carve(chunk, g.grad_rows, P * GROWX);
+  if (end) *end = chunk;
   return g;
 }
 inline size_t geom_bytes(size_t P) {
-  GeomState g = geom_from_chunk(nullptr, P);
-  return reinterpret_cast<size_t>(g.grad_rows + P * GROWX) + 256;
+  size_t end = 0;
+  geom_from_chunk(nullptr, P, &end);
+  return end + 256;  // slack for a chunk that is not itself 256-byte aligned
 }
-inline BinningState binning_from_chunk(char *chunk, size_t R, size_t tiles = 0) {
+inline BinningState binning_from_chunk(char *chunk_, size_t R, size_t tiles = 0, size_t *end = nullptr) {
   BinningState b;
+  uintptr_t chunk = carve_begin(chunk_);
   size_t n = R ? R : 1;
   carve(chunk, b.keys_a, n);
   carve(chunk, b.vals_a, n);
@@ -107,23 +114,28 @@ inline BinningState binning_from_chunk(char *chunk, size_t R, size_t tiles = 0) 
     carve(chunk, b.tile_counts, tiles * 16);  // one counter per 64-byte line (binning_bucket.hip CSTRIDE)
     carve(chunk, b.tile_cursor, tiles);
   }
+  if (end) *end = chunk;
   return b;
 }
 inline size_t binning_bytes(size_t R, size_t tiles) {
-  BinningState b = binning_from_chunk(nullptr, R, tiles ? tiles : 1);
-  return reinterpret_cast<size_t>(b.tile_cursor + (tiles ? tiles : 1)) + 256;
+  size_t end = 0;
+  binning_from_chunk(nullptr, R, tiles ? tiles : 1, &end);
+  return end + 256;
 }
-inline ImageState image_from_chunk(char *chunk, size_t npix, size_t tiles) {
+inline ImageState image_from_chunk(char *chunk_, size_t npix, size_t tiles, size_t *end = nullptr) {
   ImageState s;
+  uintptr_t chunk = carve_begin(chunk_);
   carve(chunk, s.final_T, npix);
   carve(chunk, s.n_contrib, npix);
   carve(chunk, s.ranges, tiles);
   carve(chunk, s.order, tiles + 1);
+  if (end) *end = chunk;
   return s;
 }
 inline size_t image_bytes(size_t npix, size_t tiles) {
-  ImageState s = image_from_chunk(nullptr, npix, tiles);
-  return reinterpret_cast<size_t>(s.order + tiles + 1) + 256;
+  size_t end = 0;
+  image_from_chunk(nullptr, npix, tiles, &end);
+  return end + 256;
 }
 
 // ---- error plumbing (gsr_api.hip) -------------------------------------------------------------

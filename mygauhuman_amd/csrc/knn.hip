@@ -34,8 +34,9 @@ static inline int knn_level(size_t P) {
   return L;
 }
 static inline int knn_red_blocks(int P) { return min(1024, (P + 1023) / 1024); }
-static KnnWorkspace knn_carve(char *p, size_t P) {
+static KnnWorkspace knn_carve(char *p_, size_t P, size_t *end = nullptr) {
   KnnWorkspace w;
+  uintptr_t p = carve_begin(p_);
   size_t n = P ? P : 1;
   carve(p, w.partial, (size_t)1024 * 6);
   carve(p, w.hdr, 1);
@@ -48,12 +49,13 @@ static KnnWorkspace knn_carve(char *p, size_t P) {
   carve(p, w.hist, sort_hist_words(n));
   carve(p, w.sorted, n);
   carve(p, w.table, (size_t)1 << (3 * knn_level(n)));
+  if (end) *end = p;
   return w;
 }
 size_t knn_workspace_bytes(size_t P) {
-  KnnWorkspace w = knn_carve(nullptr, P);
-  size_t n = P ? P : 1;
-  return reinterpret_cast<size_t>(w.table + ((size_t)1 << (3 * knn_level(n)))) + 512;
+  size_t end = 0;
+  knn_carve(nullptr, P, &end);
+  return end + 512;
 }
 
 __device__ __forceinline__ float wave_min(float v) {

@@ -117,8 +117,18 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
         ctx.watch = None
         if sync_free:  # no host read of num_rendered: generous capacity + deferred overflow check (_C.AsyncCapacity)
             out = _C.rasterize_gaussians_async(*args, extra=extra)
-            ctx.watch = out[9]
-            out = out[:9]
+            watch, out = out[9], out[:9]
+            # a frame that will have a backward is examined there, before the optimizer can consume its gradients.  A frame
+            # that will NOT (evaluation under no_grad, render.py-style loops) has nobody to examine a deferred flag: it waits for
+            # its own flag words here, with the whole frame already queued -- an overflow raises on this very call, like the
+            # reference's blocking path, which sizes the buffer and always renders
+            will_backward = torch.is_grad_enabled() and any(
+                isinstance(t, torch.Tensor) and t.requires_grad for t in (means3D, means2D, sh, colors_precomp, extra, opacities,
+                                                                          scales, rotations, cov3Ds_precomp))
+            if will_backward:
+                ctx.watch = watch
+            elif watch is not None:
+                _C.AsyncCapacity.check(watch)
         else:
             out = _C.rasterize_gaussians(*args, extra=extra)
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra = out

@@ -18,37 +18,61 @@ Rules of a captured region (violations bake a stale pointer or an unqueryable ob
   * stage profiling (gsr_profile_enable) must be off;
   * ROCm 7.2: the HIP runtime's graph packet capture must be off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which importing this
     package sets if the HIP runtime is not up yet): with it, replays go wrong as soon as other GPU work runs between them.
+    Whether the flag really took effect cannot be known from Python (torch.cuda.is_available() or a device count may have
+    started the runtime before the variable was set), so a GraphedFrame VERIFIES ITSELF once after the capture: one replay,
+    unrelated eager GPU work (the condition under which the bad mode fails), a second replay, and both compared with the eager
+    warm-up step; a mismatch raises instead of handing wrong gradients to an optimizer.
 """
+import os
+
 import torch
 
 from . import GRAPH_REPLAY_SAFE
 from .diff_gaussian_rasterization import _C
 
 
+def _tensors_of(result):
+    """The floating-point tensors inside whatever step_fn returned (a tensor, a dict / list / tuple of them, or nothing)."""
+    if isinstance(result, torch.Tensor):
+        return [result] if result.is_floating_point() else []
+    if isinstance(result, dict):
+        result = list(result.values())
+    if isinstance(result, (list, tuple)):
+        return [t for t in result if isinstance(t, torch.Tensor) and t.is_floating_point()]
+    return []
+
+
 class GraphedFrame:
-    def __init__(self, step_fn, warmup=3, zero_grads=None, debug_dump=None):
+    def __init__(self, step_fn, warmup=3, zero_grads=None, debug_dump=None, verify=True, verify_rtol=2e-3):
         """step_fn is called `warmup` times eagerly on a side stream (allocator / caches settle), then once under capture.
         zero_grads: optional iterable of parameters whose .grad is set to None before the capture, so that the captured
-        backward allocates them from the graph's pool (they stay valid between replays)."""
-        if not GRAPH_REPLAY_SAFE:
+        backward allocates them from the graph's pool (they stay valid between replays).
+        verify: replay twice with unrelated eager GPU work in between and compare the gradients (and the tensors step_fn returns)
+        with the eager warm-up step to verify_rtol of each tensor's largest magnitude (float atomics reorder sums; the failure
+        this guards against is off by many orders of magnitude); raises RuntimeError on a mismatch."""
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" or not GRAPH_REPLAY_SAFE:
             raise RuntimeError("GraphedFrame: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP runtime "
-                               "starts (import mygauhuman_amd before the first torch.cuda call, or export it): on ROCm 7.2 graph "
+                               "starts (export it, or import mygauhuman_amd before the first torch.cuda call): on ROCm 7.2 graph "
                                "replays over torch allocations return wrong results otherwise")
         self.step_fn = step_fn
+        params = list(zero_grads) if zero_grads is not None else []
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        eager_result = None
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                if zero_grads is not None:
-                    for p in zero_grads:
-                        p.grad = None
-                step_fn()
+            for _ in range(max(1, warmup)):
+                for p in params:
+                    p.grad = None
+                eager_result = step_fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         _C.AsyncCapacity.check_all()
-        if zero_grads is not None:
-            for p in zero_grads:
-                p.grad = None
+        # what the eager step produced: the reference of the self-check below
+        eager_ref = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        eager_ref += [t.detach().clone() for t in _tensors_of(eager_result)]
+        del eager_result
+        for p in params:
+            p.grad = None
         n0 = len(_C.AsyncCapacity.graph_status)
         self.graph = torch.cuda.CUDAGraph()
         if debug_dump:
@@ -63,8 +87,42 @@ class GraphedFrame:
         self._status = _C.AsyncCapacity.graph_status[n0:]
         del _C.AsyncCapacity.graph_status[n0:]
         # the gradients the captured backward writes: tensors of the graph's pool, re-attached at every replay
-        self._params = list(zero_grads) if zero_grads is not None else []
+        self._params = params
         self._grads = [p.grad for p in self._params]
+        if verify:
+            self._verify(eager_ref, verify_rtol)
+
+    def _verify(self, eager_ref, rtol):
+        """One replay, unrelated eager GPU work (a fill, a reduction with a device-to-host read, a fresh allocation: what an
+        optimizer step or a logging call does between frames), a second replay; both must reproduce the eager step."""
+        live = [g for g in self._grads] + _tensors_of(self.result)
+        if len(live) != len(eager_ref):
+            return  # step_fn returns something else per call: nothing comparable
+
+        def compare(tag):
+            torch.cuda.synchronize()
+            for k, (got, want) in enumerate(zip(live, eager_ref)):
+                if got is None or want is None or got.shape != want.shape:
+                    continue
+                scale = float(want.abs().max())
+                err = float((got.float() - want.float()).abs().max())
+                if not (err <= rtol * scale + 1e-30) or not bool(torch.isfinite(got).all()):
+                    raise RuntimeError(
+                        f"GraphedFrame self-check failed ({tag}, tensor {k}: max error {err:.3e} against a magnitude of {scale:.3e}): "
+                        "the replayed graph does not reproduce the eager step.  On ROCm 7.2 this is what the HIP runtime's graph "
+                        "packet capture does to graphs over torch allocations -- DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the "
+                        "environment BEFORE the first HIP call of the process (torch.cuda.is_available() counts).")
+        self.replay()
+        compare("first replay")
+        dev = live[0].device if live else torch.device("cuda")
+        junk = torch.empty(1 << 22, device=dev)
+        junk.fill_(2.0)
+        float(junk.sum())
+        junk2 = torch.empty(1 << 24, device=dev)
+        junk2.fill_(1.0)
+        del junk, junk2
+        self.replay()
+        compare("replay after unrelated eager GPU work")
 
     def replay(self):
         self.graph.replay()

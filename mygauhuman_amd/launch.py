@@ -29,9 +29,16 @@ def spawn_ranks(argv, world, env=None, timeout=None, rehearse_on_one_device=None
     base.update(env or {})
     base.setdefault("MASTER_ADDR", "127.0.0.1")
     base["MASTER_PORT"] = str(free_port())
+    # dmabuf IPC: the host driver of the GPU pool supports no other kind, and RCCL / device-tensor sharing between processes
+    # fails with `hipIpcGetMemHandle: invalid argument` in the legacy mode (the pool exports this itself; a rank started from
+    # an environment that lost it -- `env -i`, a scheduler -- still gets it)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # read by the HIP runtime of every rank when it starts (graph.py): set here so that no rank depends on its import order
+    base.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
     if rehearse_on_one_device is None:
-        rehearse_on_one_device = torch.cuda.device_count() < world  # counting devices does not initialise the GPU
+        # (device_count() may start the HIP runtime in THIS process -- harmless: the parent launches ranks and exits with their
+        # status, it neither captures graphs nor execs)
+        rehearse_on_one_device = torch.cuda.device_count() < world
     if rehearse_on_one_device:
         base.setdefault("GSR_SINGLE_DEVICE", "1")
         base.setdefault("GSR_DIST_BACKEND", "gloo")

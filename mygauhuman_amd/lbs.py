@@ -77,24 +77,34 @@ def shape_offsets(smpl, shapes):
 class _FrameConstants:
     """Results that depend only on tensors which stay the same frame after frame (a camera's big-pose parameters, a subject's
     betas): recomputed only when one of the input tensors is another tensor or was written to.  Key = (address, version,
-    shape, device) of every input; the entry keeps the inputs alive, so an address cannot be handed to different data while
-    the entry lives.  Only used for inputs outside the autograd graph.  LRU."""
+    shape, device, dtype) of every input AND of the SMPL tables the values are computed from (`smpl_keys`: an in-place edit of
+    posedirs / shapedirs / J_regressor invalidates the entry); the entry keeps the inputs alive, so an address cannot be handed
+    to different data while the entry lives.  Bypassed -- plain recomputation -- for inputs inside the autograd graph, for
+    inference tensors (they have no version counter) and while a stream is being captured into a graph (memory of a graph's
+    private pool must not end up in a process-wide cache).  LRU, a few hundred entries: two per (camera, subject) pair."""
 
-    def __init__(self, capacity=4096):
+    def __init__(self, capacity=256):
         from collections import OrderedDict
         self.capacity, self.entries = capacity, OrderedDict()
 
-    def get(self, tag, smpl, tensors, compute):
-        if any(t.requires_grad for t in tensors) or torch.is_grad_enabled() and any(t.grad_fn is not None for t in tensors):
+    @staticmethod
+    def _sig(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype)
+
+    def get(self, tag, smpl, tensors, compute, smpl_keys=()):
+        tables = tuple(smpl[k] for k in smpl_keys)
+        everything = tuple(tensors) + tables
+        if (any(t.requires_grad for t in everything) or torch.is_grad_enabled() and any(t.grad_fn is not None for t in everything)
+                or any(t.is_inference() for t in everything) or (everything[0].is_cuda and torch.cuda.is_current_stream_capturing())):
             return compute()
-        key = (tag, id(smpl)) + tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in tensors)
+        key = (tag, id(smpl)) + tuple(self._sig(t) for t in everything)
         hit = self.entries.get(key)
         if hit is not None:
             self.entries.move_to_end(key)
             return hit[1]
         with torch.no_grad():
             value = compute()
-        self.entries[key] = ((smpl,) + tuple(tensors), value)
+        self.entries[key] = ((smpl,) + everything, value)
         if len(self.entries) > self.capacity:
             self.entries.popitem(last=False)
         return value
@@ -166,15 +176,17 @@ def smpl_pose_transforms(smpl, params, correct_Rs=None):
     # constants of the SMPL model and are cached on the dict (the per-frame [24 x 6890] x [6890 x 3] product is a one-tile,
     # K = 6890 rocBLAS launch of 60 us)
     cache = smpl.get("_joint_tables")
-    if cache is None or cache[0] != nb:
+    sig = (nb,) + tuple(_FrameConstants._sig(smpl[k]) for k in ("J_regressor", "v_template", "shapedirs"))
+    if cache is None or cache[0] != sig:
         with torch.no_grad():
             Jt = torch.matmul(smpl["J_regressor"], smpl["v_template"])                                       # [24, 3]
             Js = torch.einsum("jv,vcl->jcl", smpl["J_regressor"], smpl["shapedirs"][..., :nb].float())       # [24, 3, nb]
-        cache = (nb, Jt.contiguous(), Js.contiguous())
+        cache = (sig, Jt.contiguous(), Js.contiguous())
         smpl["_joint_tables"] = cache
     # (a subject's betas are the same tensor frame after frame: the small product is cached on it)
     joints = _CONSTANTS.get("joints", smpl, (betas,),
-                            lambda: cache[1] + torch.matmul(cache[2], betas.reshape(-1, 1).float()).squeeze(-1))
+                            lambda: cache[1] + torch.matmul(cache[2], betas.reshape(-1, 1).float()).squeeze(-1),
+                            smpl_keys=("J_regressor", "v_template", "shapedirs"))
     rot, A = _SmplPose.apply(params["poses"], correct_Rs, joints, parents_host(smpl))
     return A[None], rot[None], joints[None]
 
@@ -301,11 +313,15 @@ def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_we
     def big_pose():
         A, rot, _ = smpl_pose_transforms(smpl, t_params)
         return A, pose_offsets(smpl, rot)
-    A_big, off_big = _CONSTANTS.get("big_pose", smpl, (t_params["poses"], t_params["shapes"]), big_pose)
+    A_big, off_big = _CONSTANTS.get("big_pose", smpl, (t_params["poses"], t_params["shapes"]), big_pose,
+                                    smpl_keys=("v_template", "shapedirs", "J_regressor", "posedirs"))
     A_pose, rot_mats, _ = smpl_pose_transforms(smpl, params, correct_Rs)
     R, Th = params["R"], params["Th"]
-    shapes = params["shapes"].to(query_pts.device)
-    off_shape = _CONSTANTS.get("shape_offsets", smpl, (shapes,), lambda: shape_offsets(smpl, shapes))
+    # keyed on the caller's OWN tensor (before any .to(device): a host tensor would be a new device copy -- a new address,
+    # never a hit -- every frame)
+    shapes_in = params["shapes"]
+    off_shape = _CONSTANTS.get("shape_offsets", smpl, (shapes_in,),
+                               lambda: shape_offsets(smpl, shapes_in.to(query_pts.device)), smpl_keys=("shapedirs",))
     off_pose = pose_offsets(smpl, rot_mats)
     o = lbs_deform(query_pts[0], None if normals is None else normals[0], None if lbs_weights is None else lbs_weights[0],
                    A_big[0], A_pose[0], off_big, off_shape, off_pose, R.reshape(3, 3), Th.reshape(-1)[:3], t_vertices[0],

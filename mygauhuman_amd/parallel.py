@@ -23,14 +23,14 @@ from ._lib import check, lib
 from .launch import free_port, spawn_ranks  # noqa: F401  (re-exported)
 
 
-def _staged(t):
+def _staged(t, group=None):
     """gloo rehearsals with device tensors: the collective runs on a host copy (ProcessGroupGloo builds without device
     support reject device tensors); RCCL takes the device tensor itself."""
-    return t.is_cuda and dist.get_backend() == "gloo"
+    return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
 def all_reduce_(t, op=dist.ReduceOp.SUM, group=None):
-    if _staged(t):
+    if _staged(t, group):
         h = t.cpu()
         dist.all_reduce(h, op=op, group=group)
         t.copy_(h)

@@ -198,6 +198,15 @@ def knn_self(points, k):
     return idx, dist
 
 
+def knn_self_boxes(points, k):
+    """knn_self's result through Morton-sorted boxes (exact, seconds at 500k points)."""
+    points = _c(points, f32)
+    P = points.shape[0]
+    idx, dist = np.zeros((P, k), np.int32), np.zeros((P, k), f32)
+    lib().oracle_knn_self_boxes(C.c_int(P), _p(points, _fp), C.c_int(k), _p(idx, _ip), _p(dist, _fp))
+    return idx, dist
+
+
 def nearest_dist(query, verts, idx):
     query, verts, idx = _c(query, f32), _c(verts, f32), np.ascontiguousarray(idx, np.int32)
     out = np.zeros(query.shape[0], f32)

@@ -1,15 +1,35 @@
 import os
 import sys
 
-import pytest
+# before anything imports torch: the HIP runtime reads this when it starts (mygauhuman_amd/__init__.py, graph.py)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _install_native_backtrace():
+    """tests/native_bt.c: a fatal signal prints the native stack and the name of the thread that raised it (faulthandler only
+    knows Python frames).  Best effort: the suite runs without it when gcc is missing."""
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, lib = os.path.join(here, "native_bt.c"), os.path.join(here, "_native_bt.so")
+    try:
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", lib, src])
+        return ctypes.CDLL(lib).native_bt_install() == 0
+    except Exception as ex:  # noqa: BLE001
+        print(f"[conftest] native backtrace handler not installed: {ex}")
+        return False
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _install_native_backtrace()
 
 
 @pytest.fixture(scope="session")

@@ -245,3 +245,56 @@ def test_fused_alpha_mask_loss_backward_equals_loss_kernel_plus_backward(P, W, H
                     util.assert_close(f"fused loss {k}", b[k].cpu().numpy(), a[k].cpu().numpy(), tol=2e-5, max_bad_frac=1e-5)
         finally:
             _lib.set_tuning("deterministic", 0)
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3"])
+def test_full_size_matches_oracle(oracle, cfg):
+    """HIP with the LIBRARY DEFAULTS (tile-bucket binning, tight tile culling, LDS-fold backward: the benched path) against the
+    CPU oracle at BASELINE.json's full sizes -- C2 = 50k / SH0 / 512^2 forward, C3 = 200k / SH3 / 1024^2 forward + backward
+    (CR/forward.cu:261-383, CR/backward.cu:399-587 at the size the bench line is quoted on).  Integer state bit-exact, tile lists
+    sublists of the reference lists in the reference order, images and all eight gradients at 1e-4 with O(1) upstream gradients
+    and no element beyond 1e-3 of its tensor's scale."""
+    import os
+    from mygauhuman_amd import synthetic
+    P, W, H, deg = (50_000, 512, 512, 0) if cfg == "C2" else (200_000, 1024, 1024, 3)
+    cam, g = _setup(P, W, H, deg)
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        ref = util.oracle_forward(oracle, cam, g, bg, "sh")
+        f = util.hip_forward(cam, g, bg, "sh")
+        pre, b, img = ref["pre"], ref["bin"], ref["img"]
+        np.testing.assert_array_equal(f["radii"].cpu().numpy(), pre["radii"])
+        assert f["R"] == b["R"]
+        np.testing.assert_array_equal(util.hip_query(f, "TILES_TOUCHED").view(np.uint32), pre["tiles_touched"])
+        np.testing.assert_array_equal(util.hip_query(f, "POINT_OFFSETS").view(np.uint32), b["offsets"])
+        vis = pre["radii"] > 0
+        for q, k in (("DEPTHS", "depths"), ("MEANS2D", "means2D"), ("CONIC_OPACITY", "conic_opacity"), ("RGB", "rgb"),
+                     ("COV3D", "cov3D"), ("CLAMPED", "clamped")):
+            np.testing.assert_array_equal(util.hip_query(f, q)[vis], pre[k][vis], err_msg=q)
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        kept = util.assert_lists_are_sublists(f, b, tiles)
+        assert 0.5 * b["R"] < kept < b["R"]
+        solid = img["fragile"] == 0
+        assert solid.mean() > 0.995
+        ncon = util.hip_query(f, "N_CONTRIB").view(np.uint32)
+        assert np.all(ncon[solid] <= img["n_contrib"][solid])
+        util.assert_close("final_T", util.hip_query(f, "FINAL_T"), img["final_T"], mask=solid)
+        for k in ("color", "depth", "alpha"):
+            util.assert_close(k, f[k].cpu().numpy(), img[k], mask=np.broadcast_to(solid, img[k].shape))
+        if cfg == "C2":
+            return
+        gt, mask = synthetic.loss_targets(W, H)
+        rng = np.random.default_rng(3)
+        # the un-normalised loss gradient of train.py:261-262 (O(1) per pixel) plus a depth gradient so that all three image
+        # gradients are live; zero on the pixels whose forward state may legitimately differ
+        dc = (np.sign(img["color"] - gt) * solid).astype(np.float32)
+        da = (0.2 * (img["alpha"] - mask) * solid).astype(np.float32)
+        dd = (rng.normal(0, 0.3, (1, H, W)) * solid).astype(np.float32)
+        want = oracle.rasterize_backward(ref, dc, dd, da)
+        got = util.hip_backward(f, dc, dd, da)
+        for n in ("dL_dmean2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+            assert float(np.abs(want[n]).max()) > 1e-2, n
+            util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=1e-4, outer_tol=1e-3)
+    finally:
+        oracle.set_threads(min(8, os.cpu_count() or 1))

@@ -49,5 +49,5 @@ def test_random_scene_forward_backward(oracle, seed):
     for n in names:
         # (one Gaussian's elements may sit on the tolerance: small tensors, float atomics in arbitrary order -- seed 85 of the
         # long sweep: dL_dcov3D off by 1.1 .. 1.7e-4 of the tensor's scale in 3 runs of 12)
-        util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=max(3e-4, 2.5 / want[n].size))
-        util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=3e-4, max_bad_frac=3e-4 if want[n].size > 5000 else 0.0)  # and nothing far off
+        # and NOTHING beyond 1e-3 of the tensor scale (util.assert_close's outer bound: zero exceptions)
+        util.assert_close(n, got[n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=max(3e-4, 2.5 / want[n].size), outer_tol=1e-3)

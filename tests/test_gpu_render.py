@@ -328,3 +328,188 @@ def test_render_with_fused_activations_equals_property_getters(oracle):
         np.testing.assert_allclose(outs[False][k], outs[True][k], atol=3e-5, err_msg=k)
     for ga, gb in zip(grads[False], grads[True]):
         util.assert_close("render grads", ga, gb, tol=1e-4, max_bad_frac=2e-4)
+
+
+def _chain64(s, leaf, ids, dec=None):
+    """The reference's per-frame chain from the model's leaf parameters to the rasterizer's inputs, in float64 torch on the CPU
+    (scene/gaussian_model.py:157-199 activations, :768-872 LBS with the nearest-vertex ids given, :35-42 covariance,
+    gaussian_renderer/__init__.py:128-198 colours and feature colours) -- the differentiable half of the oracle composition.
+    leaf: dict of float64 leaf tensors (requires_grad); dec: optional dict(delta [23,3,3], w [24]) of the motion decoders."""
+    from tests.test_gpu_lbs import _torch_deform
+    from tests.torch_reference import frame_attributes_torch, smpl_pose_transforms_torch
+    t64 = lambda a: torch.as_tensor(np.asarray(a, np.float64))  # noqa: E731
+    m = s.m
+    smpl = dict(v_template=t64(m["v_template"]), shapedirs=t64(m["shapedirs"]), posedirs=t64(m["posedirs"]),
+                J_regressor=t64(m["J_regressor"]), weights=t64(m["weights"]),
+                kintree_table=torch.from_numpy(np.stack([PARENTS, np.arange(24)]).astype(np.int64)))
+    V = m["v_template"].shape[0]
+    big = dict(poses=t64(BIG_POSE[None]), shapes=t64(np.zeros((1, 10))), R=t64(np.eye(3)), Th=t64(np.zeros((1, 3))))
+    tgt = dict(poses=t64(s.pose[None]), shapes=t64(s.betas[None]), R=t64(s.R), Th=t64(s.Th[None]))
+    correct_Rs = None if dec is None else (torch.eye(3, dtype=torch.float64)[None] + dec["delta"])[None]
+    A_big, rot_big, _ = smpl_pose_transforms_torch(smpl, big)
+    A_pose, rot_pose, _ = smpl_pose_transforms_torch(smpl, tgt, correct_Rs)
+    ident = torch.eye(3, dtype=torch.float64)
+    pd = smpl["posedirs"].reshape(V * 3, -1)
+    off_big = (pd @ (rot_big[0, 1:] - ident).reshape(-1)).view(V, 3)
+    off_pose = (pd @ (rot_pose[0, 1:] - ident).reshape(-1)).view(V, 3)
+    off_shape = (smpl["shapedirs"] @ tgt["shapes"].reshape(-1, 1)).squeeze(-1)
+    opacity, albedo = torch.sigmoid(leaf["opacity"]), torch.sigmoid(leaf["albedo"])
+    scaling = torch.exp(leaf["scaling"])
+    rot_n = leaf["rotation"] / leaf["rotation"].norm(dim=1, keepdim=True)
+    normal = leaf["normal"] / leaf["normal"].norm(dim=1, keepdim=True)
+    P = leaf["xyz"].shape[0]
+    loff = None if dec is None else dec["w"][None].expand(P, 24)
+    world, transforms, world_normal = _torch_deform(leaf["xyz"], normal, loff, A_big[0], A_pose[0], off_big, off_shape, off_pose,
+                                                    tgt["R"], tgt["Th"].reshape(3), torch.from_numpy(ids.astype(np.int64)),
+                                                    smpl["weights"])
+    shs = torch.cat((leaf["f_dc"], leaf["f_rest"]), dim=1)
+    c = s.cam_np
+    cov6, colors, features = frame_attributes_torch(world, transforms, world_normal, scaling, 1.0, leaf["rotation"], rot_n, albedo,
+                                                    albedo, opacity.repeat(1, 3), shs, 3, t64(c["campos"]), t64(c["viewmatrix"]))
+    return dict(means3D=world, cov6=cov6, colors=colors, features=features, opacity=opacity, transforms=transforms)
+
+
+@pytest.mark.parametrize("motion", [False, True], ids=["static_weights", "motion_decoders"])
+def test_render_features_and_parameter_gradients_match_oracle_composition(oracle, motion):
+    """render() end to end against the oracle composition, all seven images and EVERY parameter gradient (VERDICT r2 #2d;
+    gaussian_renderer/__init__.py:203-272):
+      (A) the pre-raster chain -- activations, LBS deform, covariance, SH colour, six feature colour sets -- HIP fp32 vs the
+          float64 torch restatement of the reference's op chain (nearest-vertex ids from the oracle);
+      (B) the seven images + alpha + depth vs SEVEN oracle rasterizer passes (precomputed-colour mode, like the reference's
+          feature passes) over the bit-identical per-Gaussian inputs, 1e-4 off the fragile pixels;
+      (C) d(loss)/d(leaf) for _xyz, _features_dc, _features_rest, _scaling, _rotation, _opacity, _normal, _albedo (and the two
+          decoder parameters) and the screen-space gradient vs  oracle.rasterize_backward (summed over the seven passes)
+          chained through float64 autograd of (A)."""
+    from mygauhuman_amd import lbs
+    from mygauhuman_amd.attributes import frame_attributes
+    from mygauhuman_amd.gaussian_renderer import render
+    s = _human_scene(oracle, seed=21, motion=motion)
+    model, c = s.model, s.cam_np
+    H, W, P = c["H"], c["W"], s.g["means3D"].shape[0]
+    dec_mods = None
+    if motion:
+        class PoseDec(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                g = torch.Generator().manual_seed(3)
+                self.delta = torch.nn.Parameter(0.02 * torch.randn((23, 3, 3), generator=g).cuda())
+
+            def forward(self, posevec):
+                return {"Rs": (torch.eye(3, device="cuda")[None] + self.delta)[None]}
+
+        class WDec(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                g = torch.Generator().manual_seed(4)
+                self.w = torch.nn.Parameter(0.3 * torch.randn((1, 24, 1), generator=g).cuda())
+
+            def forward(self, pts):
+                return self.w.expand(1, 24, pts.shape[1])
+
+        dec_mods = (PoseDec(), WDec())
+        model.pose_decoder, model.lweight_offset_decoder = dec_mods
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    out = render(1, s.cam, model, pipe, util.to_dev(bg))
+
+    # ---- the HIP path's own per-Gaussian rasterizer inputs (the same deterministic kernels render() just ran)
+    with torch.no_grad():
+        act = model.frame_activations()
+        cr = lw = None
+        if motion:
+            cr = dec_mods[0](s.cam.smpl_param["poses"][:, 3:])["Rs"]
+            lw = dec_mods[1](model.get_xyz[None]).permute(0, 2, 1)
+        _, world, _, tf, _, wn = lbs.coarse_deform_c2source(model.SMPL_NEUTRAL, model.get_xyz[None], s.cam.smpl_param,
+                                                            s.cam.big_pose_smpl_param, s.cam.big_pose_world_vertex[None],
+                                                            lbs_weights=lw, correct_Rs=cr, normals=act.normal[None], lean=True)
+        cov_h, col_h, feat_h = frame_attributes(world.reshape(-1, 3), tf.reshape(-1, 3, 3), wn.reshape(-1, 3), act.scaling, 1.0,
+                                                model._rotation, act.rotation, act.albedo, act.roughness, act.occlusion,
+                                                (model._features_dc, model._features_rest), 3, s.cam.camera_center,
+                                                s.cam.world_view_transform)
+    hip = dict(means3D=world.reshape(-1, 3).cpu().numpy(), cov6=cov_h.cpu().numpy(), colors=col_h.cpu().numpy(),
+               features=feat_h.cpu().numpy(), opacity=act.opacity.cpu().numpy())
+    assert torch.equal(out["transforms"].detach(), tf)
+
+    # ---- (A) float64 chain
+    ids = oracle.nearest_vertex(s.g["means3D"], s.big_verts)
+    names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "normal", "albedo")
+    leaf = {n: p.detach().cpu().double().requires_grad_(True) for n, p in zip(names, model.parameters())}
+    dec64 = None
+    if motion:
+        dec64 = dict(delta=dec_mods[0].delta.detach().cpu().double().requires_grad_(True),
+                     w=dec_mods[1].w.detach().cpu().double().reshape(24).requires_grad_(True))
+    ch = _chain64(s, leaf, ids, dec64)
+    for k in ("means3D", "cov6", "colors", "features", "opacity"):
+        util.assert_close(f"chain {k}", hip[k], ch[k].detach().numpy().reshape(hip[k].shape), tol=2e-5)
+
+    # ---- (B) seven oracle passes over the HIP path's own inputs
+    sets = [hip["colors"]] + [np.ascontiguousarray(hip["features"][:, 3 * k:3 * k + 3]) for k in range(6)]
+    keys = ("render", "normal", "world_normal", "albedo", "occlusion", "roughness", "render_axis")
+    refs = [oracle.rasterize_forward(hip["means3D"], hip["opacity"], c["viewmatrix"], c["projmatrix"], c["campos"], W, H,
+                                     c["tanfovx"], c["tanfovy"], bg, cov3D_precomp=hip["cov6"], colors_precomp=cs) for cs in sets]
+    solid = refs[0]["img"]["fragile"] == 0
+    assert solid.mean() > 0.99 and float((refs[0]["pre"]["radii"] > 0).mean()) > 0.9
+    np.testing.assert_array_equal(out["radii"].cpu().numpy(), refs[0]["pre"]["radii"])
+    m3 = np.broadcast_to(solid, (3, H, W))
+    for k, r in zip(keys, refs):
+        util.assert_close(k, out[k].detach().cpu().numpy(), r["img"]["color"], mask=m3)
+    util.assert_close("render_alpha", out["render_alpha"].detach().cpu().numpy(), refs[0]["img"]["alpha"], mask=solid[None])
+    util.assert_close("render_depth", out["render_depth"].detach().cpu().numpy(), refs[0]["img"]["depth"], mask=solid[None])
+
+    # ---- (C) gradients: random image weights (zero on fragile pixels), all seven images + alpha + depth live
+    rng = np.random.default_rng(5)
+    Wk = [(rng.normal(0, 1, (3, H, W)) * solid).astype(np.float32) for _ in keys]
+    Wa, Wd = ((rng.normal(0, 1, (1, H, W)) * solid).astype(np.float32) for _ in range(2))
+    loss = sum((out[k] * util.to_dev(w)).sum() for k, w in zip(keys, Wk))
+    loss = loss + (out["render_alpha"] * util.to_dev(Wa)).sum() + (out["render_depth"] * util.to_dev(Wd)).sum()
+    loss.backward()
+    zero1 = np.zeros((1, H, W), np.float32)
+    g_mean, g_cov, g_op, g_m2d, g_sets = 0.0, 0.0, 0.0, 0.0, []
+    for k, (r, w) in enumerate(zip(refs, Wk)):
+        b = oracle.rasterize_backward(r, w, Wd if k == 0 else zero1, Wa if k == 0 else zero1)
+        g_mean, g_cov = g_mean + b["dL_dmeans3D"].astype(np.float64), g_cov + b["dL_dcov3D"].astype(np.float64)
+        g_op, g_m2d = g_op + b["dL_dopacity"].astype(np.float64), g_m2d + b["dL_dmean2D"].astype(np.float64)
+        g_sets.append(b["dL_dcolors"].astype(np.float64))
+    util.assert_close("viewspace_points.grad", out["viewspace_points"].grad.cpu().numpy(), g_m2d.reshape(P, 3), tol=2e-4,
+                      max_bad_frac=2e-4, outer_tol=2e-3)
+    t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))  # noqa: E731
+    outs = [ch["means3D"], ch["cov6"], ch["colors"], ch["features"], ch["opacity"]]
+    gouts = [t64(g_mean), t64(g_cov), t64(g_sets[0]), t64(np.concatenate(g_sets[1:], axis=1)), t64(g_op.reshape(P, 1))]
+    inputs = list(leaf.values()) + ([dec64["delta"], dec64["w"]] if motion else [])
+    want = torch.autograd.grad(outs, inputs, gouts)
+    got = [p.grad for p in model.parameters()] + ([dec_mods[0].delta.grad, dec_mods[1].w.grad.reshape(24)] if motion else [])
+    for n, g, wnt in zip(names + (("pose_decoder.delta", "lweight_offset_decoder.w") if motion else ()), got, want):
+        assert g is not None and float(wnt.abs().max()) > 0, n
+        util.assert_close(f"d{n}", g.cpu().numpy().reshape(wnt.shape), wnt.numpy(), tol=3e-4, max_bad_frac=2e-4, outer_tol=3e-3)
+
+
+def test_forward_only_render_raises_on_the_overflowing_call(oracle, monkeypatch):
+    """under no_grad (render.py-style evaluation) nobody would examine a deferred overflow flag -- a frame whose
+    binning capacity is too small must raise on the SAME render() call, not hand back a background-only image; the capacity
+    has been raised by then, so the retry renders."""
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    from mygauhuman_amd.gaussian_renderer import render
+    s = _human_scene(oracle, seed=13)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    bg = util.to_dev(np.array([0.2, 0.3, 0.1], np.float32))
+    with torch.no_grad():
+        good = render(1, s.cam, s.model, pipe, bg)["render"].clone()
+    _C.AsyncCapacity.check_all()
+    real = _C.AsyncCapacity.capacity
+    calls = []
+
+    def tiny(P, device=None):
+        calls.append(P)
+        return 512 if len(calls) == 1 else real(P, device)
+    monkeypatch.setattr(_C.AsyncCapacity, "capacity", tiny)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="exceeded the binning capacity"):
+            render(1, s.cam, s.model, pipe, bg)
+        again = render(1, s.cam, s.model, pipe, bg)["render"]
+    assert torch.equal(again, good)
+    # with a backward to come the check stays deferred (the host does not wait inside forward): the raise comes from backward()
+    calls.clear()
+    out = render(1, s.cam, s.model, pipe, bg)
+    with pytest.raises(RuntimeError, match="exceeded the binning capacity"):
+        out["render"].mean().backward()
+    _C.AsyncCapacity.check_all()

@@ -68,6 +68,34 @@ def test_dist2_matches_oracle_bit_exact(oracle, P):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("P,log_scale", [(200_000, "cloud"), (500_000, "cloud"), (500_000, "surface")])
+def test_dist2_and_knn_at_bench_sizes(oracle, P, log_scale):
+    """distCUDA2 and knn_self at the sizes BASELINE configs[2] / configs[4] run them (the grid depth L of csrc/knn.hip depends
+    on P: L = 6 at 200k, 7 at 500k -- sizes the brute-force comparisons above never reach).  Checker: the oracle's Morton-box
+    restatement of SK/simple_knn.cu:185-221 (== brute force on small clouds: tests/test_oracle_selfcheck.py) and its box-pruned
+    exact k-NN; results bit-exact (dist2) / index-exact with lowest-index ties (k-NN)."""
+    import os
+    from mygauhuman_amd import knn_cuda
+    from mygauhuman_amd.simple_knn._C import distCUDA2
+    rng = np.random.default_rng(P // 1000)
+    pts = rng.normal(0, 1, (P, 3)).astype(np.float32) * np.array([0.9, 0.9, 0.15], np.float32)
+    if log_scale == "surface":   # a thin shell: most grid cells empty, a few crowded
+        pts = (pts / np.linalg.norm(pts, axis=1, keepdims=True) * (1.0 + 0.002 * rng.normal(0, 1, (P, 1)))).astype(np.float32)
+    pts[: P // 50] = pts[P // 50: 2 * (P // 50)]  # coincident points -> zero distances and index ties
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        want = oracle.dist2_morton(pts)[0]
+        dev = util.to_dev(pts)
+        np.testing.assert_array_equal(distCUDA2(dev).cpu().numpy(), want)
+        for k in (2, 3):
+            wi, wd = oracle.knn_self_boxes(pts, k)
+            d, i = knn_cuda.knn_self(dev, k)
+            np.testing.assert_array_equal(i.cpu().numpy(), wi)
+            np.testing.assert_allclose(d.cpu().numpy(), wd, rtol=2e-7, atol=0)
+    finally:
+        oracle.set_threads(min(8, os.cpu_count() or 1))
+
+
 def test_dist2_clustered_and_shifted(oracle):
     """Clusters far from the origin (the AABB always contains the origin, SK/simple_knn.cu:191) + a degenerate axis."""
     from mygauhuman_amd.simple_knn._C import distCUDA2

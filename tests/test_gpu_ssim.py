@@ -46,3 +46,24 @@ def test_ssim_per_image_mode_identical_images_and_fallbacks():
         loss_utils.ssim(x, y, window_size=7)
     with pytest.raises(RuntimeError):
         loss_utils.ssim(x.cpu(), y.cpu())
+
+
+def test_ssim_against_the_conv2d_formulation_on_the_device():
+    """The grouped-conv2d checker evaluated ON THE DEVICE (MIOpen) for the shape whose backward preceded round 2's one
+    unexplained abort (gpurun_out/r2_t13.log: `(1.0 - r).backward()`, shape (1, 1, 300, 517), conv2d backward on autograd's
+    device thread).  Round 3 put it back here after the host layer came out clean under ASan / UBSan / TSan
+    (tests/test_host_layer_sanitized.py) and the kernels' writes were fenced by guard bands (tests/test_gpu_guardband.py); with
+    tests/native_bt.c installed (conftest.py) an abort in this process now prints the native stack and the thread's name."""
+    from mygauhuman_amd import loss_utils
+    shape = (1, 1, 300, 517)
+    g = torch.Generator().manual_seed(sum(shape))
+    img2 = torch.rand(shape, generator=g).cuda()
+    img1 = (img2 + 0.2 * torch.randn(shape, generator=g).cuda()).clamp(0, 1).requires_grad_(True)
+    ref1 = img1.detach().clone().requires_grad_(True)
+    v = loss_utils.ssim(img1, img2)
+    r = ssim_torch(ref1, img2)
+    assert abs(float(v.detach()) - float(r.detach())) < 2e-6
+    (1.0 - v).backward()
+    (1.0 - r).backward()
+    scale = float(ref1.grad.abs().max())
+    assert float((img1.grad - ref1.grad).abs().max()) < 1e-4 * scale

@@ -149,3 +149,23 @@ def test_dist2_morton_equals_brute(oracle):
         b, codes, order = oracle.dist2_morton(pts)
         np.testing.assert_array_equal(a, b)
         assert np.all(np.diff(codes[order].astype(np.int64)) >= 0)
+
+
+@pytest.mark.parametrize("kind", ["normal", "duplicates", "grid", "tiny"])
+def test_knn_boxes_equals_brute(oracle, kind):
+    """The box-pruned exact k-NN that checks the HIP k-NN at 200k / 500k points == the brute-force definition (indices incl.
+    lowest-index ties, distance bits)."""
+    rng = np.random.default_rng(11)
+    P = 5000
+    pts = rng.normal(0, 1, (P, 3)).astype(np.float32)
+    if kind == "duplicates":
+        pts = np.concatenate([pts[:P // 2], pts[:P // 2]]).astype(np.float32)
+    elif kind == "grid":
+        pts = np.stack(np.meshgrid(np.arange(15), np.arange(20), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    elif kind == "tiny":
+        pts = pts[:3]
+    for k in (1, 2, 3):
+        k = min(k, pts.shape[0])
+        a, b = oracle.knn_self(pts, k), oracle.knn_self_boxes(pts, k)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])

@@ -68,11 +68,14 @@ def hip_backward(f, dL_dcolor, dL_ddepth, dL_dalpha, debug=False):
     return {n: o.cpu().numpy() for n, o in zip(names, out)}
 
 
-def assert_close(name, got, want, tol=1e-4, mask=None, max_bad_frac=0.0, atol=0.0):
+def assert_close(name, got, want, tol=1e-4, mask=None, max_bad_frac=0.0, atol=0.0, outer_tol=None):
     """|got - want| <= tol * max(|want|, scale) + atol elementwise, where scale = the tensor's OWN 99.9th percentile
     magnitude (sums of many +/- terms are accurate relative to the terms, not to the possibly cancelled result).  There is no
     built-in absolute floor: a tensor of tiny gradients is held to tol relative to its own size (pass atol where an
-    absolute floor is meant)."""
+    absolute floor is meant).
+    max_bad_frac > 0 lets that fraction of the elements sit outside `tol` (float atomics in arbitrary order put the odd element
+    on the tolerance) -- but NO element, without exception, may be further off than outer_tol (default 10 x tol) by the same
+    measure: a defect that hits one Gaussian in thousands with an arbitrarily wrong value fails whatever the fraction."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, (name, got.shape, want.shape)
     if got.size == 0:
@@ -85,6 +88,12 @@ def assert_close(name, got, want, tol=1e-4, mask=None, max_bad_frac=0.0, atol=0.
     bad = err > bound
     if mask is not None:
         bad &= mask
+    far = err > (10.0 * tol if outer_tol is None else outer_tol) * np.maximum(np.abs(want), scale) + atol
+    if mask is not None:
+        far &= mask
+    assert not far.any(), (f"{name}: {far.sum()} / {far.size} elements beyond the outer bound; worst index "
+                           f"{np.unravel_index(np.argmax(np.where(far, err, 0)), err.shape)} err {err[far].max():.3e} "
+                           f"want {want.flat[np.argmax(np.where(far, err, 0))]:.3e} (scale {scale:.3e})")
     frac = bad.mean()
     assert frac <= max_bad_frac, (f"{name}: {bad.sum()} / {bad.size} elements off; max err {err[bad].max():.3e} "
                                   f"(scale {scale:.3e}, tol {tol:g}, atol {atol:g})")
