@@ -864,7 +864,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;
-    GSR_HIP(hipMemsetAsync(b.tile_counts, 0, tiles * CSTRIDE * sizeof(uint32_t), stream));
+    GSR_HIP(zero_async(b.tile_counts, tiles * CSTRIDE * sizeof(uint32_t), stream));
     if (opt.tile_cull)
       hipLaunchKernelGGL(bucket_count_kernel<true>, dim3(pre_blocks(P)), dim3(PRE_BLOCK), 0, stream, g, radii, P, grid_x, grid_y,
                          b.tile_counts, b.vals_a, cap32, CSTRIDE);

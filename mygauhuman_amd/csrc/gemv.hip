@@ -82,7 +82,7 @@ int gsr_gemv_rows_t(int rows, int cols, const float *mat, const float *dout, flo
     return GSR_EINVAL;
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  GSR_HIP(hipMemsetAsync(dvec, 0, sizeof(float) * cols, stream));
+  GSR_HIP(zero_async(dvec, sizeof(float) * cols, stream));
   if (rows == 0) return GSR_OK;
   const int rows_per_wave = 48;
   const int waves = (rows + rows_per_wave - 1) / rows_per_wave;

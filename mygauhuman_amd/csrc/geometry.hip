@@ -367,8 +367,8 @@ __global__ void tile_ranges_kernel(size_t R, const uint64_t *keys, uint2 *ranges
   if (idx == R - 1) ranges[cur].y = (uint32_t)R;
 }
 int launch_tile_ranges(size_t R, const uint64_t *keys_sorted, uint2 *ranges, size_t tiles, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(ranges, 0, tiles * sizeof(uint2), stream);
-  if (e != hipSuccess) return check_hip(e, "hipMemsetAsync(ranges)", __FILE__, __LINE__);
+  hipError_t e = zero_async(ranges, tiles * sizeof(uint2), stream);
+  if (e != hipSuccess) return check_hip(e, "zero_async(ranges)", __FILE__, __LINE__);
   if (R == 0) return GSR_OK;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R, keys_sorted, ranges);
   return GSR_OK;

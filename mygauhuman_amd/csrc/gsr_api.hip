@@ -368,7 +368,7 @@ int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStrea
   pa.prefiltered = in.prefiltered;
   pa.sh_half = in.sh_half;
   // flag word of the prefiltered contract (see preprocess_forward_kernel); untouched and unread unless prefiltered is set
-  if (in.prefiltered) GSR_HIP(hipMemsetAsync(geom.total + 1, 0, sizeof(uint32_t), stream));
+  if (in.prefiltered) GSR_HIP(zero_async(geom.total + 1, sizeof(uint32_t), stream));
   prof_begin(PROF_PREPROCESS_FWD, stream);
   int rc = launch_preprocess_forward(pa, stream);
   prof_end(PROF_PREPROCESS_FWD, stream);
@@ -412,7 +412,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
     if (rc != GSR_OK) return rc;
     rc = launch_tile_ranges(R, bin.keys_s, img.ranges, tiles, stream);
     if (rc != GSR_OK) return rc;
-    GSR_HIP(hipMemsetAsync(img.order + tiles, 0, sizeof(uint32_t), stream));  // natural tile order
+    GSR_HIP(zero_async(img.order + tiles, sizeof(uint32_t), stream));  // natural tile order
     GSR_LAUNCH_CHECK(stream, in.debug);
   }
   prof_end(PROF_BINNING, stream);
@@ -626,9 +626,9 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
   if (opt.deterministic) {  // one 64-byte slot per (instance, quadrant), zeroed: culled instances keep zeros
     // (a test mode: plain hipMalloc / hipFree around the call, no stream-ordered pool involved)
     GSR_HIP(hipMalloc(reinterpret_cast<void **>(&det_rows), det_bytes));
-    GSR_HIP(hipMemsetAsync(det_rows, 0, det_bytes, stream));
+    GSR_HIP(zero_async(det_rows, det_bytes, stream));
   } else if (!(flags & GSR_BWD_ROWS_ZEROED)) {
-    GSR_HIP(hipMemsetAsync(geom.grad_rows, 0, (size_t)P * grow * sizeof(float), stream));
+    GSR_HIP(zero_async(geom.grad_rows, (size_t)P * grow * sizeof(float), stream));
   }
   BlendBwdArgs ba;
   memset(&ba, 0, sizeof(ba));

@@ -347,6 +347,30 @@ __device__ __forceinline__ bool ellipse_hits_rect(float gx, float gy, float A, f
   return qmin <= thr;
 }
 
+// Zero-fill as a KERNEL, not as a hipMemsetAsync: under the HIP runtime's graph packet capture (ROCm 7.2 default) a memset NODE
+// on memory of a hipGraph's private pool replays wrong once other GPU work has run between two replays
+// (tools/graph_bisect.py, profiles/r3_graph_bisect.txt: a bare hipMemsetAsync + one torch add, no libgsr involved, is off by
+// 3e32; a kernel writing the same memory is right).  The library therefore records no memset nodes at all.
+static __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *p, size_t n_words) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n_words; i += stride) {
+    if (i + 4 <= n_words && (reinterpret_cast<uintptr_t>(p + i) & 15) == 0) {
+      *reinterpret_cast<uint4 *>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (size_t k = i; k < n_words && k < i + 4; k++) p[k] = 0u;
+    }
+  }
+}
+// bytes must be a multiple of 4 (every array of the library is made of 4-byte words or larger)
+static inline hipError_t zero_async(void *p, size_t bytes, hipStream_t stream) {
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  const size_t groups = (n + 1023) / 1024;  // 256 threads x 4 words
+  const unsigned grid = (unsigned)(groups < 2048 ? groups : 2048);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(p), n);
+  return hipGetLastError();
+}
+
 // wave64 inclusive scan (uint32 add) with shuffles
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   const uint32_t lane = lane_id();

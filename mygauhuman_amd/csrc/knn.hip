@@ -230,7 +230,7 @@ static int knn_build(int P, const float *points, const KnnWorkspace &w, int L, h
   if (rc != GSR_OK) return rc;
   const bool in_x = radix_passes(end_bit) % 2 == 1;
   const uint32_t *ks = in_x ? w.tk : w.keys_s, *is = in_x ? w.tv : w.idx_s;
-  GSR_HIP(hipMemsetAsync(w.table, 0, sizeof(uint2) * ((size_t)1 << (3 * L)), stream));
+  GSR_HIP(zero_async(w.table, sizeof(uint2) * ((size_t)1 << (3 * L)), stream));
   hipLaunchKernelGGL(gather_table_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, ks, is, w.sorted, w.table);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;

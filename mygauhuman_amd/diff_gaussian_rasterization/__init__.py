@@ -122,9 +122,9 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             # that will NOT (evaluation under no_grad, render.py-style loops) has nobody to examine a deferred flag: it waits for
             # its own flag words here, with the whole frame already queued -- an overflow raises on this very call, like the
             # reference's blocking path, which sizes the buffer and always renders
-            will_backward = torch.is_grad_enabled() and any(
-                isinstance(t, torch.Tensor) and t.requires_grad for t in (means3D, means2D, sh, colors_precomp, extra, opacities,
-                                                                          scales, rotations, cov3Ds_precomp))
+            # (inside Function.forward grad mode is always off: ctx.needs_input_grad is what says whether autograd recorded this
+            # call -- all False under no_grad or when no input requires grad)
+            will_backward = any(ctx.needs_input_grad)
             if will_backward:
                 ctx.watch = watch
             elif watch is not None:
