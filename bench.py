@@ -271,6 +271,191 @@ def extra_workload(name, dev, steps=60, warmup=5):
             "instances_after_tile_cull": ls["instances_after_tile_cull"]}
 
 
+RENDER_WL = dict(P=200_000, V=6890, W=1024, H=1024, desc="render(): 200k articulated Gaussians (LBS -> attributes -> fused 21-channel "
+                 "raster), 1024x1024, fwd+bwd, phase-1 loss (image, alpha, normal, axis)")
+PHASE1_KEYS = ("render", "render_alpha", "normal", "render_axis")   # the images train.py:256-286 puts in the loss before the PBR phase
+
+
+def _render_pipe():
+    import types
+    return types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+
+
+def _phase1_loss(out):
+    return sum(out[k].mean() for k in PHASE1_KEYS)
+
+
+def render_extra(dev, steps=40, warmup=30):
+    """render() forward + backward at 200k articulated Gaussians / 1024^2 through the drop-in signature
+    (gaussian_renderer/__init__.py:53), eager and as ONE hipGraph replay (mygauhuman_amd.graph.GraphedFrame) -- VERDICT r2 #5."""
+    import torch
+
+    from mygauhuman_amd import human_synth
+    from mygauhuman_amd.gaussian_renderer import render
+    from mygauhuman_amd.graph import GraphedFrame
+    wl = RENDER_WL
+    model, body = human_synth.build(wl["P"], wl["V"], dev, seed=0)
+    cam = human_synth.view_camera(body, wl["W"], wl["H"], 0, n_views=8, device=dev)
+    bg, pipe, params = torch.zeros(3, device=dev), _render_pipe(), list(model.parameters())
+
+    def step():
+        o = render(1, cam, model, pipe, bg)
+        _phase1_loss(o).backward()
+        return o["render"]
+
+    def eager():
+        for p in params:
+            p.grad = None
+        step()
+    for _ in range(warmup):
+        eager()
+    el, per = timed(eager, steps, torch.cuda.synchronize)
+    out = {"workload": wl["desc"], "eager": {"value": round(steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4),
+                                             "step_ms": pct(per)}}
+    try:
+        frame = GraphedFrame(step, warmup=3, zero_grads=params)   # verifies itself (replay / eager work / replay vs eager)
+        for _ in range(5):
+            frame.replay()
+        el, per = timed(frame.replay, steps, torch.cuda.synchronize)
+        frame.check()
+        out["one_graph"] = {"value": round(steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per),
+                            "self_check": "passed"}
+    except RuntimeError as ex:   # never silent: the line says why there is no graph number
+        out["one_graph"] = {"error": str(ex)[:300]}
+    return out
+
+
+def dropin_extra(dev, steps=60, warmup=10):
+    """C3 forward + backward through the DROP-IN operator surface, the way train.py would call it: GaussianRasterizer(...)(...)
+    under autograd (diff_gaussian_rasterization/__init__.py:190-223) with the reference's blocking read of num_rendered
+    (CR/rasterizer_impl.cu:283) every forward, torch ops for the alpha-mask loss -- VERDICT r2 #5."""
+    import torch
+
+    from mygauhuman_amd import cameras, synthetic
+    from mygauhuman_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    wl = WORKLOADS["C3"]
+    P, W, H, deg = wl["P"], wl["W"], wl["H"], wl["deg"]
+    g = synthetic.uniform_gaussians(P, seed=0, sh_degree=deg)
+    gt, mask = synthetic.loss_targets(W, H, seed=0)
+    cam = cameras.make_camera(W, H, 50.0)
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    t = {k: to(g[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    rast = GaussianRasterizer(GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+        viewmatrix=to(cam["viewmatrix"]), projmatrix=to(cam["projmatrix"]), sh_degree=deg, campos=to(cam["campos"]), prefiltered=False,
+        debug=False))
+    gt_d, mask_d = to(gt), to(mask)
+
+    def step():
+        for v in t.values():
+            v.grad = None
+        means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+        color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
+                                          scales=t["scales"], rotations=t["rotations"])
+        loss = (color - gt_d).abs().mean() + 0.1 * ((alpha - mask_d) ** 2).mean()
+        loss.backward()
+    for _ in range(warmup):
+        step()
+    el, per = timed(step, steps, torch.cuda.synchronize)
+    return {"workload": "C3 through GaussianRasterizer + autograd (blocking num_rendered read per forward, torch-op loss)",
+            "value": round(steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per)}
+
+
+def c5_parts_extra(dev, reps=20):
+    """The two C5 items of BASELINE.md §4 that are not the rasterizer: per-frame LBS deform and distCUDA2, at 500k points."""
+    import torch
+
+    from mygauhuman_amd import human_synth, lbs
+    from mygauhuman_amd.simple_knn._C import distCUDA2
+    P = WORKLOADS["C5"]["P"]
+    model, body = human_synth.build(P, RENDER_WL["V"], dev, seed=0)
+    cam = human_synth.view_camera(body, 1024, 1024, 0, n_views=8, device=dev)
+    xyz, nrm = model.get_xyz.detach(), torch.nn.functional.normalize(model._normal.detach())
+
+    def deform():
+        return lbs.coarse_deform_c2source(model.SMPL_NEUTRAL, xyz[None], cam.smpl_param, cam.big_pose_smpl_param,
+                                          cam.big_pose_world_vertex[None], normals=nrm[None], lean=True)
+
+    def deform_fb():
+        q = xyz.clone().requires_grad_(True)
+        o = lbs.coarse_deform_c2source(model.SMPL_NEUTRAL, q[None], cam.smpl_param, cam.big_pose_smpl_param,
+                                       cam.big_pose_world_vertex[None], normals=nrm[None], lean=True)
+        (o[1].sum() + o[3].sum()).backward()
+    res = {}
+    with torch.no_grad():
+        for _ in range(3):
+            deform()
+        el, _ = timed(deform, reps, torch.cuda.synchronize, per_step_events=False)
+        res["lbs_forward_ms"] = round(el / reps * 1e3, 4)
+    for _ in range(3):
+        deform_fb()
+    el, _ = timed(deform_fb, reps, torch.cuda.synchronize, per_step_events=False)
+    res["lbs_forward_backward_ms"] = round(el / reps * 1e3, 4)
+    for _ in range(3):
+        distCUDA2(xyz)
+    el, _ = timed(lambda: distCUDA2(xyz), reps, torch.cuda.synchronize, per_step_events=False)
+    res["dist2_ms"] = round(el / reps * 1e3, 4)
+    res["points"] = P
+    res["what"] = ("coarse_deform_c2source (pose kernels + blend-shape GEMV + per-point LBS kernel, frame constants cached) and distCUDA2 "
+                   "(blocking, as the reference calls it) at 500k points, wall ms per call")
+    return res
+
+
+def main_render(a, rank, world, local, dev, rehearsal):
+    """--workload render: the view-parallel TRAINING step of the articulated model (parallel.ViewParallelRender): every rank renders
+    its own ring camera / pose through render(), phase-1 loss, autograd backward, then the exchange of every leaf gradient and of
+    the densification statistics.  N = 1: the same step without an exchange."""
+    import torch
+    import torch.distributed as dist
+
+    from mygauhuman_amd import human_synth, parallel
+    wl = RENDER_WL
+    P = int(os.environ.get("GSR_BENCH_P", wl["P"]))
+    model, body = human_synth.build(P, wl["V"], dev, seed=0, motion=True)
+    cam = human_synth.view_camera(body, wl["W"], wl["H"], rank, n_views=8, device=dev)
+    bg = torch.zeros(3, device=dev)
+    step = parallel.ViewParallelRender(model, _render_pipe(), bg)
+
+    def one():
+        step(1, cam, _phase1_loss)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(3, a.warmup)):
+        one()
+    sync()
+    step.check()
+    step.timer.reset()
+    elapsed, per_step = timed(one, a.steps, sync)
+    step.check()
+    ex = step.timer.read_ms()
+    t = torch.tensor([elapsed, float(np.mean(ex)) if ex else 0.0], dtype=torch.float64, device=dev)
+    if world > 1:
+        parallel.all_reduce_(t, dist.ReduceOp.MAX)
+    elapsed, exchange_ms = float(t[0]), float(t[1])
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        out = {"metric": "frames/sec render() fwd+bwd @1024^2, 200k articulated Gaussians (view-parallel training step)",
+               "value": round(world * a.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": wl["desc"] + f"; S-human seed 0, {world} ring view(s)/step, 1 view/rank, own pose per view; "
+                          + ("REHEARSAL: all ranks on ONE device over gloo with host-staged collectives -- not a scaling number; "
+                             if rehearsal else "") + f"exchange payload {step.payload_bytes / 1e6:.1f} MB/rank"
+                          + (" (compact SH: all-gather + all-reduce)" if step.compact is not None else " (one all-reduce)"),
+                          "P": P, "width": wl["W"], "height": wl["H"], "leaves": list(step.leaves),
+                          "backend": (dist.get_backend() if world > 1 else None)},
+               "step_ms": pct(per_step), "exchange_ms": round(exchange_ms, 4), "step_compute_ms": round(ms - exchange_ms, 4),
+               "splatted_gaussians_per_s": round(world * a.steps / elapsed * P, 1)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+
 def self_launch(a, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script and return their status.
     Runs before anything has touched the GPU (no HIP call, no libgsr.so): the parent only waits."""
@@ -285,7 +470,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS) + ["render"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the forward-only / C2 / C5 figures")
     ap.add_argument("--binning", type=int, default=-1, help="0 global radix, 1 tile bucket (default: library default)")
@@ -311,6 +496,8 @@ def main():
     for kv in a.tune:
         k, v = kv.split("=")
         _lib.set_tuning(k, int(v))
+    if a.workload == "render":
+        return main_render(a, rank, world, local, dev, rehearsal)
 
     sc = Scene(a.workload, rank, world, dev)
     wl, P, W, H, M = sc.wl, sc.P, sc.W, sc.H, sc.M
@@ -334,14 +521,17 @@ def main():
     _lib.profile_enable([dominant])  # only the dominant kernel keeps its two event records in the timed region
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
+    if sc.step is not None:
+        sc.step.timer.reset()
     elapsed, per_step = timed(sc.one_step, a.steps, sync)
+    ex_ms = sc.step.timer.read_ms() if sc.step is not None else []
     ls = sc.list_stats()  # (synchronises; after the timed region)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(np.mean(ex_ms)) if ex_ms else 0.0], dtype=torch.float64, device=dev)
     Rt = torch.tensor([float(ls["instances_after_tile_cull"])], dtype=torch.float64, device=dev)
     if world > 1:
         parallel.all_reduce_(t, dist.ReduceOp.MAX)
         parallel.all_reduce_(Rt, dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    elapsed, exchange_ms = float(t[0]), float(t[1])
     sc.check()
     dom_ms, dom_n = _lib.profile_read()[dominant]
     _lib.profile_enable([])
@@ -402,6 +592,10 @@ def main():
                        "binning": "tile_bucket" if _lib.lib.gsr_get_binning_mode() == 1 else "global_radix",
                        "host_sync_per_step": 0, "backend": (dist.get_backend() if world > 1 else None)},
             "step_ms": pct(per_step),
+            # N > 1: HIP events around the collectives of every step (max over ranks of the per-rank mean) and what is left of the
+            # step -- so that a scaling run says where its time went
+            "exchange_ms": round(exchange_ms, 4) if world > 1 else None,
+            "step_compute_ms": round(ms_per_step - exchange_ms, 4) if world > 1 else None,
             "splatted_gaussians_per_s": round(fps * P, 1),
             "instances_per_s": round(float(Rt.item()) * a.steps / elapsed, 1),
             "roofline": roof,
@@ -426,6 +620,13 @@ def main():
         for name in ("C2", "C5"):
             if name != a.workload:
                 extra[name] = extra_workload(name, dev)
+        torch.cuda.empty_cache()
+        # the drop-in surface and the non-rasterizer C5 items
+        extra["dropin_rasterizer_c3"] = dropin_extra(dev)
+        torch.cuda.empty_cache()
+        extra["render_200k"] = render_extra(dev)
+        torch.cuda.empty_cache()
+        extra["c5_lbs_dist2"] = c5_parts_extra(dev)
         out["extra"] = extra
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:  # the CPU baseline is reported by the 1-GPU run only

@@ -345,6 +345,20 @@ int gsr_sh_view_pack(int P, const char *geom_buffer, const float *dL_dcolor, flo
 int gsr_sh_grad_from_views(int P, int sh_degree, int M, int n_views, const float *means3D, const float *views,
                            size_t view_stride, float scale, const float *dev_scale, float *dL_dsh, gsr_stream_t stream);
 
+/* The same exchange for ARTICULATED Gaussians (render(): colours come from the per-frame attribute kernel, and every view poses
+ * the Gaussians differently, so the positions travel with the view).  A view block is [P*3 masked dL_dRGB | ... ] with the
+ * posed positions at means_offset (>= 3 P, floats) and the camera position at cam_offset (>= means_offset + 3 P):
+ *   gsr_sh_view_pack_posed: fills the three parts of this rank's block in one launch; `colors` = the forward's colours
+ *     max(SH + 0.5, 0) (a channel that came out 0 was clamped: its gradient is dropped, gaussian_renderer/__init__.py:195),
+ *     dL_dcolors = the rasterizer's gradient with respect to them, means3D_view = the view's posed positions, campos device [3].
+ *   gsr_sh_grad_from_views_posed: the mean SH gradient written in the model's two parameter layouts, dL_dsh_dc [P][1][3] and
+ *     dL_dsh_rest [P][15][3] (16-byte aligned); scale / dev_scale as above. */
+int gsr_sh_view_pack_posed(int P, const float *colors, const float *dL_dcolors, const float *means3D_view, const float *campos,
+                           float *view_block, size_t means_offset, size_t cam_offset, gsr_stream_t stream);
+int gsr_sh_grad_from_views_posed(int P, int sh_degree, int n_views, const float *views, size_t view_stride, size_t means_offset,
+                                 size_t cam_offset, float scale, const float *dev_scale, float *dL_dsh_dc, float *dL_dsh_rest,
+                                 gsr_stream_t stream);
+
 /* Bookkeeping of one view-parallel step around its gradient all-reduce, one single-thread launch, no host read
  * (extension).  status = dev_status of the step's gsr_rasterize_forward_async (R, overflow flag); overflow_slot = one float
  * inside the all-reduced gradient bucket.
@@ -355,6 +369,12 @@ int gsr_sh_grad_from_views(int P, int sh_degree, int M, int n_views, const float
  *   phase 2: both (single process). */
 int gsr_step_status(int phase, const uint32_t *status, float *overflow_slot, float inv_world, float *scale, uint32_t *report,
                     gsr_stream_t stream);
+/* gsr_step_status phase 1 AND the division of the reduced bucket in ONE launch: bucket[0 .. n_floats) is the flat fp32 buffer
+ * that was SUM all-reduced (16-byte aligned), bucket[overflow_index] the number of ranks whose binning overflowed; every other
+ * element is multiplied by scale = (that count > 0 ? 0 : inv_world); scale[0] (optional) and report[0..2] (optional; status may
+ * be null: words 1, 2 are then 0) as in phase 1. */
+int gsr_step_finish(const uint32_t *status, float *bucket, size_t n_floats, size_t overflow_index, float inv_world, float *scale,
+                    uint32_t *report, gsr_stream_t stream);
 
 /* SMPL pose -> joint transforms (batch size 1): rodrigues of the 24 axis-angle vectors (angle = |theta + 1e-8|), the
  * optional pose-refinement product R_j <- R_j correct_Rs[j-1] (j >= 1), the kinematic chain and the removal of the rest
@@ -418,7 +438,8 @@ int gsr_frame_attributes_forward(int P, int sh_degree, int M, const float *means
  * dL_dcov3D[P][6], dL_dcolors[P][3], dL_dfeatures[P][18] may each be null (= zero).  Every outgoing array is fully
  * written (no accumulation): dL_dmeans3D[P][3] (view-direction dependence of the colours), dL_dtransforms[P][9],
  * dL_dworld_normals[P][3], dL_dscales[P][3], dL_drot_cov[P][4], dL_drot_axis[P][4], dL_dalbedo / dL_droughness /
- * dL_docclusion [P][3], dL_dshs[P][M][3] (required iff shs is given). */
+ * dL_docclusion [P][3], dL_dshs[P][M][3] (needs shs; may be null for M = 16 when the caller does not want the SH gradient -- the
+ * view-parallel compact exchange rebuilds it from dL_dcolors, gsr_sh_grad_from_views_posed). */
 int gsr_frame_attributes_backward(int P, int sh_degree, int M, const float *means3D, const float *transforms,
                                   const float *world_normals, const float *scales, float scale_modifier,
                                   const float *rot_cov, const float *rot_axis, const float *albedo,

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
-    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_backward_workgroups", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_step_status", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_model_activations_forward", "gsr_model_activations_backward", "gsr_frame_attributes_forward_split", "gsr_frame_attributes_backward_split",
+    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_backward_workgroups", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_sh_view_pack_posed", "gsr_sh_grad_from_views_posed", "gsr_step_status", "gsr_step_finish", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_model_activations_forward", "gsr_model_activations_backward", "gsr_frame_attributes_forward_split", "gsr_frame_attributes_backward_split",
 ]
 
 GSR_OK = 0
@@ -107,6 +107,10 @@ def _load():
     lib.gsr_sh_view_pack.restype = lib.gsr_sh_grad_from_views.restype = C.c_int
     lib.gsr_step_status.argtypes = [C.c_int, vp, fp, C.c_float, fp, vp, vp]
     lib.gsr_step_status.restype = C.c_int
+    lib.gsr_sh_view_pack_posed.argtypes = [C.c_int, fp, fp, fp, fp, fp, sz, sz, vp]
+    lib.gsr_sh_grad_from_views_posed.argtypes = [C.c_int, C.c_int, C.c_int, fp, sz, sz, sz, C.c_float, fp, fp, fp, vp]
+    lib.gsr_step_finish.argtypes = [vp, fp, sz, sz, C.c_float, fp, vp, vp]
+    lib.gsr_sh_view_pack_posed.restype = lib.gsr_sh_grad_from_views_posed.restype = lib.gsr_step_finish.restype = C.c_int
     lib.gsr_knn_self.argtypes = [C.c_int, fp, C.c_int, ip, fp, vp, sz, vp]
     lib.gsr_knn_nearest.argtypes = [C.c_int, fp, C.c_int, fp, ip, fp, vp, sz, vp]
     lib.gsr_knn_self.restype = lib.gsr_knn_nearest.restype = C.c_int

@@ -8,9 +8,26 @@ Returns (cov3D [P,6], colors [P,3] or None, features [P,18]) with
 features = cat(normal, world_normal, albedo, occlusion, roughness.mean x3, axis) -- the `extra` operand of
 diff_gaussian_rasterization.rasterize_gaussians_multi.
 """
+import contextlib
+
 import torch
 
 from ._lib import check, lib, ptr
+
+# view-parallel compact SH exchange (parallel.ViewParallelRender): while a sink is installed, the backward of the attribute
+# kernel hands (forward colours, dL_dcolours, posed positions) to it -- the three things the rank-one SH gradient of a view is
+# made of -- and skips the SH gradient itself when autograd does not ask for it (detached SH tensors)
+_SH_SINK = None
+
+
+@contextlib.contextmanager
+def sh_gradient_sink(sink):
+    global _SH_SINK
+    prev, _SH_SINK = _SH_SINK, sink
+    try:
+        yield sink
+    finally:
+        _SH_SINK = prev
 
 
 class _FrameAttributes(torch.autograd.Function):
@@ -36,13 +53,16 @@ class _FrameAttributes(torch.autograd.Function):
                 ptr(colors), ptr(features), torch.cuda.current_stream(dev).cuda_stream), "gsr_frame_attributes_forward")
         ctx.has_shs = shs is not None
         ctx.has_rest = rest is not None
-        ctx.save_for_backward(*([t for t in ins if t is not None] + ([rest] if rest is not None else [])))
+        ctx.sink = _SH_SINK if shs is not None else None
+        ctx.save_for_backward(*([t for t in ins if t is not None] + ([rest] if rest is not None else [])
+                                + ([colors] if ctx.sink is not None else [])))
         ctx.meta = (float(scale_modifier), int(sh_degree), M, transforms.shape)
         return cov3D, (colors if colors is not None else torch.empty(0, device=dev)), features
 
     @staticmethod
     def backward(ctx, g_cov, g_colors, g_features):
         saved = list(ctx.saved_tensors)
+        colors_fwd = saved.pop() if ctx.sink is not None else None
         rest = saved.pop() if ctx.has_rest else None
         if not ctx.has_shs:
             saved.insert(9, None)
@@ -55,8 +75,11 @@ class _FrameAttributes(torch.autograd.Function):
         new = lambda *s: torch.empty(s, dtype=f32, device=dev)  # noqa: E731
         d_means, d_T, d_wn, d_scales, d_rc, d_ra = new(P, 3), new(P, 9), new(P, 3), new(P, 3), new(P, 4), new(P, 4)
         d_alb, d_rough, d_occ = new(P, 3), new(P, 3), new(P, 3)
-        d_shs = new(P, M - (rest.shape[1] if rest is not None else 0), 3) if ctx.has_shs else None
-        d_rest = new(P, rest.shape[1], 3) if rest is not None else None
+        want_sh = ctx.has_shs and (ctx.needs_input_grad[9] or (rest is not None and ctx.needs_input_grad[14]) or M != 16)
+        d_shs = new(P, M - (rest.shape[1] if rest is not None else 0), 3) if want_sh else None
+        d_rest = new(P, rest.shape[1], 3) if (rest is not None and want_sh) else None
+        if ctx.sink is not None and g_colors is not None:
+            ctx.sink.collect(colors_fwd, g_colors, means3D)
         with torch.cuda.device(dev):
             check(lib.gsr_frame_attributes_backward_split(
                 P, D, M, ptr(means3D), ptr(transforms), ptr(wn), ptr(scales), mod, ptr(rot_cov), ptr(rot_axis), ptr(albedo),

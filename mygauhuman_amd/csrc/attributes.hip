@@ -393,7 +393,7 @@ __global__ __launch_bounds__(ATTR_BLOCK) void attributes_kernel(const AttrArgs a
       else
         attributes_forward_one(a, i, row);
     }
-    if (BWD) {
+    if (BWD && a.d_shs) {  // (d_shs == null: the caller does not want the SH gradient -- view-parallel compact exchange)
       __syncthreads();
       if (a.shs_rest) {
         float *dc = a.d_shs + (size_t)first * 3;
@@ -453,8 +453,9 @@ extern "C" {
 
 static int split_ok(const char *who, int M, const void *dc, const void *rest, const void *d_dc, const void *d_rest, bool bwd) {
   if (!rest) return GSR_OK;
+  const bool no_grad = bwd && !d_dc && !d_rest;  // both null: the SH gradient is not wanted
   if (!dc || M != gsr::ASH_M || reinterpret_cast<size_t>(rest) % 16 != 0 ||
-      (bwd && (!d_dc || !d_rest || reinterpret_cast<size_t>(d_rest) % 16 != 0))) {
+      (bwd && !no_grad && (!d_dc || !d_rest || reinterpret_cast<size_t>(d_rest) % 16 != 0))) {
     gsr::set_error("%s: split SH arrays need M = 16, the DC array and 16-byte aligned [P][15][3] arrays", who);
     return GSR_EINVAL;
   }
@@ -547,8 +548,13 @@ int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float
                         rot_axis, albedo, roughness, occlusion, shs, campos, viewmatrix);
   if (rc != GSR_OK) return rc;
   if (P > 0 && (!dL_dmeans3D || !dL_dtransforms || !dL_dworld_normals || !dL_dscales || !dL_drot_cov || !dL_drot_axis ||
-                !dL_dalbedo || !dL_droughness || !dL_docclusion || (shs && !dL_dshs))) {
+                !dL_dalbedo || !dL_droughness || !dL_docclusion)) {
     set_error("gsr_frame_attributes_backward: null output array");
+    return GSR_EINVAL;
+  }
+  // dL_dshs == null (and dL_dshs_rest == null): the SH gradient is not produced -- only in the staged 16-coefficient layouts
+  if (P > 0 && shs && !dL_dshs && !(M == ASH_M && (shs_rest || reinterpret_cast<size_t>(shs) % 16 == 0))) {
+    set_error("gsr_frame_attributes_backward: dL_dshs may only be omitted for M = 16 (16-byte aligned or split SH arrays)");
     return GSR_EINVAL;
   }
   if (P == 0) return GSR_OK;
@@ -563,7 +569,7 @@ int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float
   a.d_rot_cov = dL_drot_cov, a.d_rot_axis = dL_drot_axis, a.d_albedo = dL_dalbedo, a.d_roughness = dL_droughness;
   a.d_occlusion = dL_docclusion, a.d_shs = dL_dshs, a.d_shs_rest = dL_dshs_rest;
   const bool stage = shs && M == ASH_M &&
-                     (shs_rest || (reinterpret_cast<size_t>(shs) % 16 == 0 && reinterpret_cast<size_t>(dL_dshs) % 16 == 0));
+                     (shs_rest || (reinterpret_cast<size_t>(shs) % 16 == 0 && reinterpret_cast<size_t>(dL_dshs) % 16 == 0));  // (null is aligned)
   const dim3 grid((P + ATTR_BLOCK - 1) / ATTR_BLOCK), block(ATTR_BLOCK);
   if (stage)
     hipLaunchKernelGGL((attributes_kernel<true, true>), grid, block, 0, stream, a);

@@ -109,7 +109,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sync_free=False):
+                sync_free=False, will_backward=True):
         rs = raster_settings
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
@@ -122,9 +122,6 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             # that will NOT (evaluation under no_grad, render.py-style loops) has nobody to examine a deferred flag: it waits for
             # its own flag words here, with the whole frame already queued -- an overflow raises on this very call, like the
             # reference's blocking path, which sizes the buffer and always renders
-            # (inside Function.forward grad mode is always off: ctx.needs_input_grad is what says whether autograd recorded this
-            # call -- all False under no_grad or when no input requires grad)
-            will_backward = any(ctx.needs_input_grad)
             if will_backward:
                 ctx.watch = watch
             elif watch is not None:
@@ -164,7 +161,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             # so that an overflow raises before the optimizer consumes these gradients
             _C.AsyncCapacity.check(ctx.watch)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_extra_in, grad_opacities, grad_scales,
-                grad_rotations, grad_cov3Ds_precomp, None, None)
+                grad_rotations, grad_cov3Ds_precomp, None, None, None)
 
 
 def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors, opacities, scales, rotations, cov3Ds_precomp,
@@ -183,8 +180,12 @@ def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors
             raise Exception("rasterize_gaussians_multi takes 1 to 6 extra colour sets")
         cols = list(extra_colors) + [torch.zeros((P, 3), dtype=means3D.dtype, device=means3D.device)] * (6 - n)
         extra = torch.cat(cols, dim=1)
+    # decided HERE, in the caller's grad mode (inside Function.forward grad mode is always off and ctx.needs_input_grad ignores it)
+    will_backward = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (means3D, means2D, sh, colors_precomp, extra, opacities, scales,
+                                                                  rotations, cov3Ds_precomp))
     out = _RasterizeGaussiansMulti.apply(means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp,
-                                         raster_settings, sync_free)
+                                         raster_settings, sync_free, will_backward)
     return out[0], out[1], out[2], out[3], list(out[4:4 + n])
 
 

@@ -50,7 +50,9 @@ class GraphedFrame:
         verify: replay twice with unrelated eager GPU work in between and compare the gradients (and the tensors step_fn returns)
         with the eager warm-up step to verify_rtol of each tensor's largest magnitude (float atomics reorder sums; the failure
         this guards against is off by many orders of magnitude); raises RuntimeError on a mismatch."""
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" or not GRAPH_REPLAY_SAFE:
+        # GSR_GRAPH_ALLOW_PACKET_CAPTURE=1 (experiments): capture anyway and let the self-check decide
+        allow = os.environ.get("GSR_GRAPH_ALLOW_PACKET_CAPTURE") == "1" and verify
+        if (os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" or not GRAPH_REPLAY_SAFE) and not allow:
             raise RuntimeError("GraphedFrame: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP runtime "
                                "starts (export it, or import mygauhuman_amd before the first torch.cuda call): on ROCm 7.2 graph "
                                "replays over torch allocations return wrong results otherwise")

@@ -98,47 +98,160 @@ def gaussian_gradient_shapes(P, M, mode="sh"):
     return OrderedDict(means3D=(P, 3), colors=(P, 3), opacity=(P, 1), cov3D=(P, 6))
 
 
-class CompactShExchange:
-    """All-gather of (masked dL_dRGB [P,3] | campos [3]) per rank + local reconstruction of the mean SH gradient."""
+class ExchangeTimer:
+    """HIP events around the collectives of every step (recorded on the compute stream the collectives are ordered on; no
+    synchronisation until read): what `exchange_ms` in the bench line is made of."""
 
-    def __init__(self, P, M, device, group=None):
-        self.P, self.M, self.group = int(P), int(M), group
+    def __init__(self):
+        self.pairs, self.pool = [], []
+
+    def begin(self, device):
+        e0, e1 = self.pool.pop() if self.pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        e0.record(torch.cuda.current_stream(device))
+        self.pairs.append((e0, e1))
+
+    def end(self, device):
+        self.pairs[-1][1].record(torch.cuda.current_stream(device))
+
+    def reset(self):
+        self.pool.extend(self.pairs)
+        self.pairs = []
+
+    def read_ms(self):
+        """Per-step exchange times of the steps since reset() (synchronises on the last one)."""
+        if not self.pairs:
+            return []
+        self.pairs[-1][1].synchronize()
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
+_SELFTEST_DONE = set()
+
+
+def collective_selftest(device, group=None):
+    """Run the two collectives of a step once on 64 floats and CHECK the results, at construction time: the first use of a
+    backend in a job (RCCL on a multi-GPU node) fails here, loudly and with its own message, not in the middle of a timed
+    loop.  Returns the all-gather form to use: "tensor" (all_gather_into_tensor, out of place) or "list" (the list form, if
+    the tensor form is refused by this backend)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    key = (id(group), str(device))
+    form = "tensor"
+    send = torch.full((64,), float(rank + 1), dtype=torch.float32, device=device)
+    recv = torch.zeros((world * 64,), dtype=torch.float32, device=device)
+    want = torch.arange(1, world + 1, dtype=torch.float32, device=device).repeat_interleave(64)
+    staged = _staged(send, group)
+    try:
+        if staged:
+            raise RuntimeError("host-staged rehearsal: list form")
+        dist.all_gather_into_tensor(recv, send, group=group)
+        if not torch.equal(recv, want):
+            raise RuntimeError("all_gather_into_tensor returned wrong data")
+    except Exception as ex:  # noqa: BLE001
+        form = "list"
+        if key not in _SELFTEST_DONE and not staged and rank == 0:
+            print(f"[mygauhuman_amd.parallel] all_gather_into_tensor unusable on backend {dist.get_backend(group)} ({ex}); "
+                  "falling back to the list form", flush=True)
+        h = send.cpu() if staged else send
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        got = torch.cat(parts).to(device)
+        if not torch.equal(got, want):
+            raise RuntimeError(f"all_gather self-test failed on backend {dist.get_backend(group)}")
+    red = send.clone()
+    all_reduce_(red, dist.ReduceOp.SUM, group)
+    if not torch.equal(red, torch.full_like(red, world * (world + 1) / 2.0)):
+        raise RuntimeError(f"all_reduce self-test failed on backend {dist.get_backend(group)}")
+    _SELFTEST_DONE.add(key)
+    return form
+
+
+class CompactShExchange:
+    """All-gather of one block per rank + local reconstruction of the mean SH gradient.
+
+    static Gaussians (ViewParallelStep):   block = [P*3 masked dL_dRGB | campos 3]; every replica holds the same positions
+    posed Gaussians (ViewParallelRender):  block = [P*3 masked dL_dRGB | P*3 positions of THIS view | campos 3 | P radii]:
+                                           every view poses the Gaussians differently (LBS), so the positions the view's SH
+                                           colours were evaluated at travel with it; the screen radii ride along for the
+                                           max-reduction of the densification statistics (train.py:403).
+    The send buffer is a tensor of its own (the pack kernel writes it; nothing is copied) and the receive buffer is
+    [world][stride]: a plain out-of-place all_gather_into_tensor -- no aliasing of send and receive memory."""
+
+    def __init__(self, P, M, device, group=None, posed=False):
+        self.P, self.M, self.group, self.posed = int(P), int(M), group, bool(posed)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.stride = (self.P * 3 + 3 + 63) // 64 * 64
+        P = self.P
+        self.means_off = P * 3 if posed else 0
+        self.cam_off = P * 6 if posed else P * 3
+        self.radii_off = self.cam_off + 4 if posed else 0
+        used = self.radii_off + P if posed else P * 3 + 3
+        self.stride = (used + 63) // 64 * 64
         self.gathered = torch.zeros((self.world, self.stride), dtype=torch.float32, device=device)
-        self.mine = self.gathered[dist.get_rank(group) if self.world > 1 else 0]
-        self.grad = torch.empty((self.P, self.M, 3), dtype=torch.float32, device=device)
+        self.mine = torch.zeros((self.stride,), dtype=torch.float32, device=device)
+        if posed:
+            self.grad_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=device)
+            self.grad_rest = torch.empty((P, 15, 3), dtype=torch.float32, device=device)
+            self.grad = None
+        else:
+            self.grad = torch.empty((P, self.M, 3), dtype=torch.float32, device=device)
+        self.form = "tensor"
+        if self.world > 1:
+            self.form = collective_selftest(torch.device(device), group)
 
     def pack(self, session, campos):
-        """Fill this rank's block from the session's last backward (its raw dL_dcolor and the forward's clamp bits)."""
-        dev = self.grad.device
+        """Static path: fill this rank's block from the session's last backward (its raw dL_dcolor + the forward's clamp bits)."""
+        dev = self.mine.device
         check(lib.gsr_sh_view_pack(self.P, session.geom.data_ptr(), session.dL_dcolors.data_ptr(), self.mine.data_ptr(),
                                    torch.cuda.current_stream(dev).cuda_stream), "gsr_sh_view_pack")
         self.mine[self.P * 3:self.P * 3 + 3].copy_(campos.reshape(3))
 
+    def pack_posed(self, colors, g_colors, means_view, campos, radii=None):
+        """Articulated path: masked dL_dRGB, this view's posed positions and camera position in one launch (+ the radii)."""
+        dev = self.mine.device
+        check(lib.gsr_sh_view_pack_posed(self.P, colors.data_ptr(), g_colors.data_ptr(), means_view.data_ptr(), campos.data_ptr(),
+                                         self.mine.data_ptr(), self.means_off, self.cam_off,
+                                         torch.cuda.current_stream(dev).cuda_stream), "gsr_sh_view_pack_posed")
+        if radii is not None:
+            self.mine[self.radii_off:self.radii_off + self.P].copy_(radii)  # int32 -> float32 (exact below 2^24 pixels)
+
+    def local(self):
+        """No exchange (single process, or an un-reduced step): this rank's block becomes view 0; reconstruct with n_views=1."""
+        self.gathered[0].copy_(self.mine)
+
     def exchange(self):
         if self.world <= 1:
+            self.local()
             return
-        if dist.get_backend() == "nccl":
-            # in-place all-gather: RCCL accepts a send buffer that IS this rank's slot of the receive buffer
-            # (sendbuff == recvbuff + rank * count), so no per-step copy of the 2.4 MB block is made
+        if self.form == "tensor" and not _staged(self.mine, self.group):
             dist.all_gather_into_tensor(self.gathered.view(-1), self.mine, group=self.group)
             return
-        # gloo (CPU tests, one-GPU rehearsals): host-staged, list form
-        src = self.mine.cpu() if self.mine.is_cuda else self.mine.clone()
+        # gloo (CPU tests, one-GPU rehearsals) or a backend without the tensor form: list form, host-staged for device tensors
+        src = self.mine.cpu() if _staged(self.mine, self.group) else self.mine
         parts = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(parts, src, group=self.group)
         self.gathered.copy_(torch.stack(parts))
 
-    def reconstruct(self, means3D, sh_degree, dev_scale=None):
-        """grad[P,M,3] = mean over the views of w_k(dir_v) * dL_dRGB_v; dev_scale: optional device float that REPLACES the
-        1 / world factor (0 for a step every replica must skip)."""
-        dev = self.grad.device
-        check(lib.gsr_sh_grad_from_views(self.P, int(sh_degree), self.M, self.world, means3D.data_ptr(), self.gathered.data_ptr(),
-                                         self.stride, 1.0 if dev_scale is not None else 1.0 / self.world,
-                                         None if dev_scale is None else dev_scale.data_ptr(), self.grad.data_ptr(),
-                                         torch.cuda.current_stream(dev).cuda_stream), "gsr_sh_grad_from_views")
+    def reconstruct(self, means3D, sh_degree, dev_scale=None, n_views=None):
+        """grad[P,M,3] (or grad_dc / grad_rest) = mean over the views of w_k(dir_v) * dL_dRGB_v; dev_scale: optional device float
+        that REPLACES the 1 / n_views factor (0 for a step every replica must skip); n_views: views 0 .. n_views-1 of the
+        receive buffer (default: all ranks)."""
+        dev = self.gathered.device
+        n_views = self.world if n_views is None else int(n_views)
+        scale = 1.0 if dev_scale is not None else 1.0 / n_views
+        ds = None if dev_scale is None else dev_scale.data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.posed:
+            check(lib.gsr_sh_grad_from_views_posed(self.P, int(sh_degree), n_views, self.gathered.data_ptr(), self.stride,
+                                                   self.means_off, self.cam_off, scale, ds, self.grad_dc.data_ptr(),
+                                                   self.grad_rest.data_ptr(), stream), "gsr_sh_grad_from_views_posed")
+            return self.grad_dc, self.grad_rest
+        check(lib.gsr_sh_grad_from_views(self.P, int(sh_degree), self.M, n_views, means3D.data_ptr(), self.gathered.data_ptr(),
+                                         self.stride, scale, ds, self.grad.data_ptr(), stream), "gsr_sh_grad_from_views")
         return self.grad
+
+    def max_radii(self, n_views=None):
+        """Max over the views of the screen radii that rode along (posed layout)."""
+        n_views = self.world if n_views is None else int(n_views)
+        return self.gathered[:n_views, self.radii_off:self.radii_off + self.P].max(dim=0).values.to(torch.int32)
 
 
 def all_reduce_densify_stats(grad_norm_accum, denom, max_radii2D, group=None):
@@ -207,6 +320,9 @@ class ViewParallelStep:
         self.pending = deque()   # (step index, pinned uint32 [ranks overflowed, R, own flag], event)
         self._pinned, self._events = [], []
         self._scale = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.timer = ExchangeTimer()
+        if world > 1:
+            collective_selftest(dev, group)
 
     @property
     def payload_bytes(self):
@@ -256,6 +372,7 @@ class ViewParallelStep:
         """Returns (color, alpha, radii); afterwards self.grads[name] holds the (mean over ranks, if reduce) gradients."""
         self._examine(block_older_than=self.steps - self.max_in_flight)
         s, b = self.session, self.bucket
+        dev = self._scale.device
         host = self._report_buffer()
         if self.world == 1:
             # single process: the forward writes its status words (R, flags) straight into this step's pinned buffer (device-
@@ -265,22 +382,251 @@ class ViewParallelStep:
         # the loss gradient is formed inside the blend-backward kernel (fastpath.backward_alpha_mask_loss): no loss kernel, no
         # gradient images
         s.backward_alpha_mask_loss(self.p, cam, bg, self.deg, gt, mask, 0.1, self.grads)
-        if reduce and self.world > 1:
-            self._status(0)
-            if self.compact is not None:
-                self.compact.pack(s, cam["campos"])
-                self.compact.exchange()
-            all_reduce_(b.flat, dist.ReduceOp.SUM, self.group)
-            self._status(1, host)
-            # scale = 1 / world, or 0 if any rank overflowed: a skipped step is skipped by every replica
-            b.flat.mul_(self._scale)
-            if self.compact is not None:
+        if self.world > 1:
+            self._status(0)  # this rank's overflow flag -> its slot of the bucket (0 / 1)
+            self.timer.begin(dev)
+            if reduce:
+                if self.compact is not None:
+                    self.compact.pack(s, cam["campos"])
+                    self.compact.exchange()
+                all_reduce_(b.flat, dist.ReduceOp.SUM, self.group)
+            else:
+                # an un-reduced step of a multi-rank job keeps its gradients local, but the ranks still AGREE on the overflow word
+                # (one 4-byte all-reduce): every rank raises BinningOverflow at the same call, or none does -- a rank that raised
+                # alone would leave its peers waiting in their next collective
+                all_reduce_(b["overflow"], dist.ReduceOp.SUM, self.group)
+            self.timer.end(dev)
+            # scale = 1 / world, or 0 if any rank overflowed (a skipped step is skipped by every replica), the whole bucket times
+            # scale and the report words: one launch (gsr_step_finish)
+            check(lib.gsr_step_finish(s.status.data_ptr(), b.flat.data_ptr(), b.flat.numel(), b.slices["overflow"][0],
+                                      (1.0 / self.world) if reduce else 1.0, self._scale.data_ptr(), host.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream), "gsr_step_finish")
+            if reduce and self.compact is not None:
                 self.compact.reconstruct(self.p["means3D"], self.deg, self._scale)
-        elif self.world > 1:  # an un-reduced step of a multi-rank job: local bookkeeping only
-            self._status(2, host)
         # (a single process needs no scaling: its own overflowed step has exactly zero gradients already)
         ev = self._events.pop() if self._events else torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self._scale.device))
         self.steps += 1
         self.pending.append((self.steps - 1, host, ev))
         return s.color, s.alpha, s.radii
+
+
+class _DetachedShModel:
+    """The model as render() reads it, with the two SH parameter tensors detached: the attribute kernel's backward then skips
+    the 192-byte-per-Gaussian SH gradient (ViewParallelRender rebuilds its mean over the views from the compact exchange)."""
+
+    def __init__(self, model):
+        object.__setattr__(self, "_m", model)
+
+    def __getattr__(self, name):
+        m = object.__getattribute__(self, "_m")
+        if name in ("_features_dc", "_features_rest"):
+            return getattr(m, name).detach()
+        return getattr(m, name)
+
+
+class _ShSink:
+    def __init__(self):
+        self.got = None
+
+    def collect(self, colors, g_colors, means_view):
+        self.got = (colors, g_colors, means_view)
+
+
+class ViewParallelRender:
+    """One view-parallel TRAINING step of the articulated model -- what train.py:212-224,401-417 does for one camera, for `world`
+    cameras at once: every rank renders its own camera / pose of the shared model through gaussian_renderer.render() (LBS deform ->
+    attributes -> fused rasterizer), evaluates the loss, runs autograd's backward, and then ONE exchange leaves on every rank
+
+      * the MEAN over the views of the gradient of every model leaf -- `_xyz, _features_dc, _features_rest, _opacity, _scaling,
+        _rotation, _normal, _albedo, _roughness` (scene/gaussian_model.py:55-127; a leaf the loss does not reach contributes
+        zeros) and every parameter of `pose_decoder` / `lweight_offset_decoder` (gaussian_renderer/__init__.py:100-106) -- in
+        `p.grad`, as views of one flat fp32 bucket (SUM all-reduce, divided on the device);
+      * the densification statistics of the step (scene/gaussian_model.py:764-766, train.py:403): the sum over the views of the
+        screen-space gradient norms of the visible Gaussians, the number of views that saw each Gaussian, the max screen radius
+        -- in `.stat_grad_norm`, `.stat_visible`, `.max_radii` (they ride in the same bucket / the same all-gather: no
+        collective of their own in the compact mode).
+
+    compact_sh (default for world > 1): the SH coefficients are 48 of the 65 gradient floats per Gaussian, and their gradient is
+    rank one per view, dL_dsh[k][c] = w_k(dir) dL_dRGB[c].  The ranks all-gather (masked dL_dRGB | posed position | radius) --
+    28 B per Gaussian -- and rebuild the mean locally with the positions EACH VIEW posed the Gaussians at (CompactShExchange,
+    posed layout); 68 B per Gaussian stay in the all-reduce instead of 260.
+
+    A rank whose binning buffer overflowed (rare: _C.AsyncCapacity sizes it generously) contributes zeros and raises the
+    overflow count in the bucket; every replica then multiplies the step by zero and raises BinningOverflow at the same later
+    call (examined `max_in_flight` steps late through pinned memory, like ViewParallelStep: no host stall)."""
+
+    MODEL_LEAVES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_normal", "_albedo", "_roughness")
+
+    def __init__(self, model, pipe, bg, group=None, compact_sh=None, max_in_flight=2):
+        self.model, self.pipe, self.bg, self.group = model, pipe, bg, group
+        dev = model.get_xyz.device
+        self.device = dev
+        self.world = world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.P = P = int(model.get_xyz.shape[0])
+        leaves = OrderedDict()
+        for n in self.MODEL_LEAVES:
+            t = getattr(model, n, None)
+            if isinstance(t, torch.Tensor) and t.numel() and t.requires_grad:
+                leaves[n] = t
+        for mod_name in ("pose_decoder", "lweight_offset_decoder"):
+            mod = getattr(model, mod_name, None)
+            if isinstance(mod, torch.nn.Module):
+                for n, p_ in mod.named_parameters():
+                    if p_.requires_grad:
+                        leaves[f"{mod_name}.{n}"] = p_
+        self.leaves = leaves
+        dc, rest = leaves.get("_features_dc"), leaves.get("_features_rest")
+        can_compact = (dc is not None and rest is not None and tuple(dc.shape) == (P, 1, 3) and tuple(rest.shape) == (P, 15, 3)
+                       and getattr(pipe, "convert_SHs_python", False) and not getattr(pipe, "separate_feature_passes", False))
+        if compact_sh is None:
+            compact_sh = world > 1 and os.environ.get("GSR_COMPACT_SH", "1") != "0"
+        self.compact = CompactShExchange(P, 16, dev, group, posed=True) if (compact_sh and can_compact) else None
+        shapes = OrderedDict((n, tuple(t.shape)) for n, t in leaves.items()
+                             if not (self.compact is not None and n in ("_features_dc", "_features_rest")))
+        shapes["stat_grad_norm"] = (P, 1)   # xyz_gradient_accum contribution of this step (scene/gaussian_model.py:765)
+        shapes["stat_visible"] = (P, 1)     # denom contribution (:766)
+        shapes["overflow"] = (1,)
+        self.bucket = GradientBucket(shapes, dev)
+        self._bucket_leaves = [n for n in shapes if n in leaves]
+        self.max_radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        self.max_in_flight = int(max_in_flight)
+        self.steps = 0
+        self.pending = deque()
+        self._pinned, self._events = [], []
+        self._scale = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.timer = ExchangeTimer()
+        self._view = _DetachedShModel(model) if self.compact is not None else model
+        if world > 1 and self.compact is None:
+            collective_selftest(dev, group)
+
+    @property
+    def stat_grad_norm(self):
+        return self.bucket["stat_grad_norm"]
+
+    @property
+    def stat_visible(self):
+        return self.bucket["stat_visible"]
+
+    @property
+    def payload_bytes(self):
+        return self.bucket.nbytes + (self.compact.stride * 4 if self.compact is not None else 0)
+
+    def accumulate_densification_stats(self):
+        """add_densification_stats + the max_radii2D update of the step (scene/gaussian_model.py:764-766, train.py:403) from the
+        statistics the exchange left: sums over ALL views of the step."""
+        m = self.model
+        m.xyz_gradient_accum += self.stat_grad_norm
+        m.denom += self.stat_visible
+        m.max_radii2D = torch.maximum(m.max_radii2D, self.max_radii.to(m.max_radii2D.dtype))
+
+    def _examine(self, block_older_than):
+        while self.pending:
+            step, host, ev = self.pending[0]
+            if step > block_older_than:
+                return
+            ev.synchronize()
+            self.pending.popleft()
+            self._events.append(ev)
+            ranks = int(host[0])
+            self._pinned.append(host)
+            if ranks > 0:
+                raise BinningOverflow(f"step {step}: {ranks} rank(s) exceeded their binning capacity; the step's gradients were "
+                                      "zeroed on every rank (the capacity of the overflowing rank has been raised) -- repeat it")
+
+    def check(self):
+        self._examine(block_older_than=self.steps)
+
+    def __call__(self, iteration, camera, loss_fn, reduce=True, **render_kw):
+        """loss_fn(out) -> scalar loss of this rank's view.  Returns (out, loss); afterwards p.grad of every leaf holds the mean
+        over the ranks (reduce=True) and the statistics of the step are in .stat_grad_norm / .stat_visible / .max_radii."""
+        from . import attributes
+        from .gaussian_renderer import render
+        self._examine(block_older_than=self.steps - self.max_in_flight)
+        dev, b = self.device, self.bucket
+        for t in self.leaves.values():
+            t.grad = None
+        sink = _ShSink() if self.compact is not None else None
+        overflowed = False
+        out = loss = None
+        try:
+            with attributes.sh_gradient_sink(sink):
+                out = render(iteration, camera, self._view, self.pipe, self.bg, **render_kw)
+                loss = loss_fn(out)
+                loss.backward()
+        except RuntimeError as ex:
+            if "exceeded the binning capacity" not in str(ex):
+                raise
+            overflowed = True   # this view rendered only the background: it contributes zeros and one count
+        # ---- this rank's contribution into the flat bucket (one multi-tensor copy) + the statistics of the step
+        if overflowed or out is None:
+            b.flat.zero_()
+            b["overflow"].fill_(1.0)
+            if self.compact is not None:
+                self.compact.mine.zero_()
+        else:
+            srcs, dsts = [], []
+            for n in self._bucket_leaves:
+                g = self.leaves[n].grad
+                if g is None:
+                    b[n].zero_()     # a leaf the loss did not reach (e.g. _roughness: get_roughness reads _albedo)
+                else:
+                    srcs.append(g)
+                    dsts.append(b[n])
+            torch._foreach_copy_(dsts, srcs)
+            vis = out["visibility_filter"]
+            vg = out["viewspace_points"].grad
+            if vg is not None:   # add_densification_stats (scene/gaussian_model.py:764-766)
+                torch.mul(torch.norm(vg[:, :2], dim=-1, keepdim=True), vis[:, None], out=b["stat_grad_norm"])
+            else:
+                b["stat_grad_norm"].zero_()
+            b["stat_visible"].copy_(vis[:, None])
+            b["overflow"].zero_()
+            if self.compact is not None:
+                if sink.got is None:
+                    raise RuntimeError("ViewParallelRender: the compact SH exchange needs render()'s python SH path "
+                                       "(pipe.convert_SHs_python = True, no override_color)")
+                colors, g_colors, means_view = sink.got
+                self.compact.pack_posed(colors, g_colors, means_view, camera.camera_center, out["radii"])
+            else:
+                self.max_radii.copy_(out["radii"])
+        host = self._pinned.pop() if self._pinned else torch.zeros(3, dtype=torch.int32).pin_memory()
+        # ---- the exchange
+        n_views = self.world if (self.world > 1 and reduce) else 1
+        if n_views > 1:
+            self.timer.begin(dev)
+            if self.compact is not None:
+                self.compact.exchange()
+            all_reduce_(b.flat, dist.ReduceOp.SUM, self.group)
+            if self.compact is None:
+                all_reduce_(self.max_radii, dist.ReduceOp.MAX, self.group)
+            self.timer.end(dev)
+        else:
+            if self.world > 1:
+                # an un-reduced step of a multi-rank job: gradients stay local, but the ranks agree on the overflow word (4 bytes)
+                all_reduce_(b["overflow"], dist.ReduceOp.SUM, self.group)
+            if self.compact is not None:
+                self.compact.local()
+        # scale = 1 / n_views (0 if any rank overflowed), the bucket times scale, the report words: one launch
+        check(lib.gsr_step_finish(None, b.flat.data_ptr(), b.flat.numel(), b.slices["overflow"][0], 1.0 / n_views,
+                                  self._scale.data_ptr(), host.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+              "gsr_step_finish")
+        if n_views > 1:  # the statistics are SUMS over the views, not means
+            b["stat_grad_norm"].mul_(float(n_views))
+            b["stat_visible"].mul_(float(n_views))
+        if self.compact is not None:
+            self.compact.reconstruct(None, self.model.active_sh_degree, self._scale, n_views=n_views)
+            self.max_radii.copy_(self.compact.max_radii(n_views))
+        # ---- p.grad = views of the bucket (and of the reconstructed SH gradient)
+        for n, t in self.leaves.items():
+            if self.compact is not None and n == "_features_dc":
+                t.grad = self.compact.grad_dc
+            elif self.compact is not None and n == "_features_rest":
+                t.grad = self.compact.grad_rest
+            else:
+                t.grad = b[n]
+        ev = self._events.pop() if self._events else torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.steps += 1
+        self.pending.append((self.steps - 1, host, ev))
+        return out, loss

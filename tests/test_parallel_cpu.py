@@ -47,6 +47,17 @@ def _worker(rank, world, port, q):
         assert torch.equal(ex.gathered[r2, :P * 3], torch.arange(P * 3, dtype=torch.float32) + 1000.0 * r2)
         assert torch.equal(ex.gathered[r2, P * 3:P * 3 + 3], torch.tensor([r2 + 0.25, r2 + 0.5, r2 + 0.75]))
     assert parallel.gaussian_gradient_shapes(P, M, "sh_compact").keys() == {"means3D", "opacity", "scales", "rotations"}
+    # the construction-time self-test of the two collectives (checks their RESULTS) and the posed block layout of render()
+    assert parallel.collective_selftest(torch.device("cpu")) in ("tensor", "list")
+    exp = parallel.CompactShExchange(P, 16, "cpu", posed=True)
+    assert (exp.means_off, exp.cam_off, exp.radii_off) == (3 * P, 6 * P, 6 * P + 4) and exp.stride % 64 == 0 and exp.stride >= 7 * P + 4
+    exp.mine.copy_(torch.arange(exp.stride, dtype=torch.float32) + 10000.0 * rank)
+    exp.mine[exp.radii_off:exp.radii_off + P].copy_(torch.arange(P, dtype=torch.float32) * (rank + 1))
+    exp.exchange()
+    for r2 in range(world):
+        assert torch.equal(exp.gathered[r2, :exp.radii_off], torch.arange(exp.radii_off, dtype=torch.float32) + 10000.0 * r2)
+    assert torch.equal(exp.max_radii(), (torch.arange(P) * world).to(torch.int32))
+    assert exp.mine.data_ptr() != exp.gathered.data_ptr()   # send and receive memory never alias
     q.put((rank, {k: v.numpy() for k, v in mine.items()}, {k: v.clone().numpy() for k, v in b.views.items()},
            acc.numpy(), den.numpy(), rad.numpy(), views))
     dist.barrier()
