@@ -74,7 +74,7 @@ __global__ __launch_bounds__(XSH_BLOCK) void sh_grad_from_views_kernel(const ShV
   if (STAGE) {
     float *row = &s_out[threadIdx.x * XSH_LDS_ROW];
 #pragma unroll
-    for (int k = 0; k < 48; k++) row[k] = acc[k] * scale;
+    for (int k = 0; k < 48; k++) row[k] = scale == 0.f ? 0.f : acc[k] * scale;  // a skipped step is exact zeros, whatever a blank view's block held
     __syncthreads();
     const int first = blockIdx.x * XSH_BLOCK;
     const int nrows = min(XSH_BLOCK, P - first);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(XSH_BLOCK) void sh_grad_from_views_kernel(const ShV
       }
     }
   } else if (i < P) {
-    for (int k = 0; k < a.M * 3; k++) a.out[(size_t)i * a.M * 3 + k] = k < 48 ? acc[k] * scale : 0.f;
+    for (int k = 0; k < a.M * 3; k++) a.out[(size_t)i * a.M * 3 + k] = (k < 48 && scale != 0.f) ? acc[k] * scale : 0.f;
   }
 }
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-KEYS = ("render", "render_alpha", "normal", "render_axis")   # the images train.py:256-286 puts in the loss before the PBR phase
+KEYS = ("render", "render_alpha", "normal", "render_axis", "albedo")   # train.py:256-286's phase-1 images + one PBR image (_albedo gets a gradient)
 
 
 def loss_of(out, weights):

@@ -70,10 +70,9 @@ def test_two_rank_render_step_equals_mean_of_view_gradients(tmp_path, compact, m
     assert int(r0["overflow_seen"][0]) == 0 and len(r0["exchange_ms"]) == 1
     for n, w in want.items():
         assert n in r0, n
-        if n == "_roughness":   # get_roughness reads _albedo (scene/gaussian_model.py:197-199): no gradient reaches _roughness
-            assert not np.any(r0[n])
+        if not np.any(w):   # _roughness always (get_roughness reads _albedo, scene/gaussian_model.py:197-199); _albedo: its image is not in this loss
+            assert n in ("_roughness", "_albedo") and not np.any(r0[n]), n
         else:
-            assert float(np.abs(w).max()) > 0, n
             util.assert_close(f"{n} rank0", r0[n].reshape(w.shape), w, tol=5e-5, max_bad_frac=1e-4, outer_tol=1e-3)
         np.testing.assert_array_equal(r0[n], r1[n], err_msg=f"{n}: replicas differ")
     util.assert_close("stat_grad_norm", r0["stat_grad_norm"], gn, tol=2e-5, max_bad_frac=1e-4, outer_tol=1e-3)
@@ -93,7 +92,7 @@ def test_render_overflow_on_one_rank_skips_the_step_on_every_rank(tmp_path):
         for n in want:
             assert not np.any(r[n]), n   # the skipped step: exact zeros on every replica
     for n, w in want.items():
-        if n == "_roughness":
+        if not np.any(w):
             continue
         util.assert_close(f"retry {n}", r0["retry_" + n].reshape(w.shape), w, tol=5e-5, max_bad_frac=1e-4, outer_tol=1e-3)
         np.testing.assert_array_equal(r0["retry_" + n], r1["retry_" + n])
@@ -114,7 +113,7 @@ def test_single_process_view_parallel_render_equals_plain_autograd():
         step(1, cam, lambda o: loss_of(o, weights))
         step.check()
         for n, w in want.items():
-            if n == "_roughness":
+            if not np.any(w):
                 continue
             util.assert_close(f"{n} compact={compact}", step.leaves[n].grad.cpu().numpy().reshape(w.shape), w, tol=5e-5, max_bad_frac=1e-4,
                               outer_tol=1e-3)
