@@ -33,6 +33,7 @@ N_EXTRA = 18  # extra feature channels of the fused multi-feature blend (six RGB
 DEFAULT_BINNING = BINNING_TILE_BUCKET
 DEFAULT_TILE_CULL = 1  # tuning knob "tile_cull": exact ellipse-vs-tile culling in the tile-bucket back-end
 DEFAULT_BWD_REDUCE = 3
+DEFAULT_TILE_ORDER = 1  # tuning knob "tile_order" (csrc/gsr_common.h: Options)
 
 
 class GsrError(RuntimeError):

@@ -53,7 +53,7 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *counts, uint32_t
                                                 uint32_t capacity, uint32_t *status, int CSTRIDE, int check_prefilter,
                                                 uint32_t *wtot, uint32_t *carry_s, uint32_t *order) {
   const uint32_t R = *total;
-  if (threadIdx.x == 0 && order) order[n] = 0u;  // natural tile order for the blend kernels (only the histogram path reorders)
+  if (threadIdx.x == 0 && order) order[0] = 0u;  // natural tile order for the blend kernels (only the histogram path reorders)
   if (threadIdx.x == 0 && status) {
     status[0] = R;
     status[1] = (R > capacity ? 1u : 0u) | ((check_prefilter && total[1]) ? 2u : 0u);
@@ -315,7 +315,8 @@ __global__ __launch_bounds__(PW *WAVE) void bucket_hist_prefix_kernel(uint32_t *
 __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState g, const uint32_t *wg_start, int tiles,
                                                                 const uint32_t *totals, const uint32_t *table, const uint32_t *rank,
                                                                 const uint32_t *gids, uint64_t *bucket, uint32_t capacity,
-                                                                uint2 *ranges, uint32_t *status, int check_prefilter, uint32_t *order, int order_mode) {
+                                                                uint2 *ranges, uint32_t *status, int check_prefilter, uint32_t *order, int order_mode,
+                                                                int grid_x) {
   constexpr int PER_MAX = (HIST_MAX_TILES + HB - 1) / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   if (R > capacity) {  // overflow: nothing is binned, every tile is empty (the caller reads the status words and regrows)
     if (blockIdx.x == 0) {
       for (int t = threadIdx.x; t < tiles; t += HB) ranges[t] = make_uint2(0u, 0u);
-      if (threadIdx.x == 0) order[tiles] = 0u;
+      if (threadIdx.x == 0) order[0] = 0u;
     }
     return;
   }
@@ -399,35 +400,92 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t b = 0, m = 0, all = 0;
-    for (int w = 0; w < HB / WAVE; w++) {
-      b += s_red[w][0];
-      m = max(m, s_red[w][1]);
-      all += s_wtot[w];  // (the waves' sums of the tile totals, from the scan above)
-    }
-    (void)b;
-    (void)all;
-    s_thr = order_mode == 0 ? 0u : m;  // Options::tile_order: 0 natural order, 1 longest lists first (default)
-    order[tiles] = s_thr ? 1u : 0u;
+    uint32_t m = 0;
+    for (int w = 0; w < HB / WAVE; w++) m = max(m, s_red[w][1]);
+    s_thr = order_mode == 0 ? 0u : m;  // Options::tile_order: 0 natural order; the longest list (0: nothing to render)
+    order[0] = s_thr ? (uint32_t)order_mode : 0u;
   }
   __syncthreads();
   const uint32_t mxn = s_thr;  // the longest list, 0: natural order (or nothing to render)
   if (mxn == 0u) return;
-  // counting sort of the tiles by list length, longest first: 64 length classes (class of n = 1 + 62 n / max, empty tiles last),
-  // the order inside a class is whatever the LDS atomics give (every tile is rendered by itself: any order of equals is as
-  // good)
   constexpr int NCLS = 64;
   __shared__ uint32_t s_ccount[NCLS], s_cbase[NCLS];
   if ((int)threadIdx.x < NCLS) s_ccount[threadIdx.x] = 0u;
+  if (order_mode == 1) {
+    // counting sort of the TILES by list length, longest first: 64 length classes (class of n = 1 + 62 n / max, empty tiles
+    // last), the order inside a class is whatever the LDS atomics give (every tile is rendered by itself: any order of equals
+    // is as good)
+    __syncthreads();
+    uint32_t mycls[PER_MAX];
+#pragma unroll
+    for (int k = 0; k < PER_MAX; k++) {
+      const int t = t0 + k;
+      mycls[k] = 0u;
+      if (k < per && t < tiles) {
+        mycls[k] = cnt[k] == 0u ? 0u : 1u + (uint32_t)(((uint64_t)cnt[k] * (NCLS - 2)) / mxn);  // 1 .. NCLS - 1
+        atomicAdd(&s_ccount[mycls[k]], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t run = 0;
+      for (int c = NCLS - 1; c >= 0; c--) {
+        s_cbase[c] = run;
+        run += s_ccount[c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_MAX; k++) {
+      const int t = t0 + k;
+      if (k < per && t < tiles) order[1 + atomicAdd(&s_cbase[mycls[k]], 1u)] = (uint32_t)t;
+    }
+    return;
+  }
+  // ---- block modes (2: 2 x 2 tiles, 3: 4 x 2 tiles): the unit that is sorted and dealt to the XCDs is a BLOCK of neighbouring
+  // tiles, by the sum of its list lengths; the tiles of a block go to visiting slots with the same slot % 8, i.e. to one XCD,
+  // back to back in that XCD's dispatch order.  Neighbouring tiles share most of their Gaussians (a splat of mean radius 13 px
+  // touches 6.6 tiles at C3): with single tiles dealt round-robin a record was fetched into up to four L2s (2 x FETCH_SIZE of
+  // the blend backward 78 -> 199 MB when the per-tile order came in, profiles/r2f_pmc.csv vs r2g_pmc.csv); a block keeps it in one.
+  // The per-tile totals go through LDS (s_base is free: every wave of this workgroup has left the scatter loop).
   __syncthreads();
-  uint32_t mycls[PER_MAX];
 #pragma unroll
   for (int k = 0; k < PER_MAX; k++) {
     const int t = t0 + k;
-    mycls[k] = 0u;
-    if (k < per && t < tiles) {
-      mycls[k] = cnt[k] == 0u ? 0u : 1u + (uint32_t)(((uint64_t)cnt[k] * (NCLS - 2)) / mxn);  // 1 .. NCLS - 1
-      atomicAdd(&s_ccount[mycls[k]], 1u);
+    if (k < per && t < tiles) s_base[t] = cnt[k];
+  }
+  __shared__ uint32_t s_bmax;
+  if (threadIdx.x == 0) s_bmax = 0u;
+  __syncthreads();
+  const int bx = order_mode == 3 ? 4 : 2, by = 2, T = bx * by;
+  const int grid_y = tiles / grid_x;
+  const int nbx = (grid_x + bx - 1) / bx, nby = (grid_y + by - 1) / by, nsb = nbx * nby;
+  constexpr int SB_PER = (HIST_MAX_TILES / 2 + 2 * 128 + HB - 1) / HB;  // blocks per thread: <= tiles / 2 + border blocks of the longest grid side
+  uint32_t bsum[SB_PER], bcls[SB_PER];
+  uint32_t lmax = 0;
+#pragma unroll
+  for (int k = 0; k < SB_PER; k++) {
+    const int sb = (int)threadIdx.x + k * HB;
+    bsum[k] = 0u;
+    if (sb < nsb) {
+      const int sx = (sb % nbx) * bx, sy = (sb / nbx) * by;
+      for (int j = 0; j < T; j++) {
+        const int tx = sx + j % bx, ty = sy + j / bx;
+        if (tx < grid_x && ty < grid_y) bsum[k] += s_base[ty * grid_x + tx];
+      }
+      lmax = max(lmax, bsum[k]);
+    }
+  }
+  if (lmax) atomicMax(&s_bmax, lmax);
+  __syncthreads();
+  const uint32_t bmx = s_bmax;
+#pragma unroll
+  for (int k = 0; k < SB_PER; k++) {
+    const int sb = (int)threadIdx.x + k * HB;
+    bcls[k] = 0u;
+    if (sb < nsb) {
+      bcls[k] = bsum[k] == 0u ? 0u : 1u + (uint32_t)(((uint64_t)bsum[k] * (NCLS - 2)) / bmx);
+      atomicAdd(&s_ccount[bcls[k]], 1u);
     }
   }
   __syncthreads();
@@ -440,9 +498,23 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < PER_MAX; k++) {
-    const int t = t0 + k;
-    if (k < per && t < tiles) order[atomicAdd(&s_cbase[mycls[k]], 1u)] = (uint32_t)t;
+  for (int k = 0; k < SB_PER; k++) {
+    const int sb = (int)threadIdx.x + k * HB;
+    if (sb < nsb) {
+      const uint32_t q = atomicAdd(&s_cbase[bcls[k]], 1u);  // sorted rank of this block
+      uint32_t *slot0 = order + 1 + (size_t)(q / 8u) * 8u * (uint32_t)T + (q % 8u);
+      const int sx = (sb % nbx) * bx, sy = (sb / nbx) * by;
+      for (int j = 0; j < T; j++) {
+        const int tx = sx + j % bx, ty = sy + j / bx;
+        slot0[(size_t)j * 8u] = (tx < grid_x && ty < grid_y) ? (uint32_t)(ty * grid_x + tx) : ORDER_NO_TILE;
+      }
+    }
+  }
+  // the last, partial group of eight blocks: padding
+  const int nsb8 = (nsb + 7) / 8 * 8;
+  for (int e = nsb * T + (int)threadIdx.x; e < nsb8 * T; e += HB) {
+    const int q = nsb + (e - nsb * T) / T, j = (e - nsb * T) % T;
+    order[1 + (size_t)(q / 8) * 8 * T + (size_t)j * 8 + q % 8] = ORDER_NO_TILE;
   }
 }
 
@@ -860,7 +932,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
       return GSR_OK;
     }
     hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
-                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order);
+                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order, grid_x);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;

@@ -129,9 +129,17 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   __shared__ uint32_t s_id[WAVE + 4];
   __shared__ uint32_t s_slot[DET ? WAVE + 4 : 1];
 
-  const bool ordered = tile_order_active(a.order, (uint32_t)(a.grid_x * a.grid_y));
-  const uint32_t item = ordered ? (WPT == 4 ? ordered_item4(blockIdx.x, (uint32_t)(a.grid_x * a.grid_y)) : blockIdx.x) : xcd_remap_b(blockIdx.x, gridDim.x);
-  const uint32_t tile = (ordered ? a.order[item / WPT] : item / WPT), part = item % WPT;
+  uint32_t tile, part;
+  if constexpr (WPT == 4) {
+    const int omode = tile_order_mode(a.order);
+    const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+    const uint32_t item = omode ? ordered_item4(blockIdx.x, n_slots) : (blockIdx.x < n_slots * 4u ? xcd_remap_b(blockIdx.x, n_slots * 4u) : n_slots * 4u);
+    tile = tile_of_slot(a.order, omode, item / 4u, n_slots), part = item % 4u;
+    if (tile == ORDER_NO_TILE) return;  // (wave-uniform) padding slot, or beyond this frame's slots
+  } else {
+    const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);  // (fewer waves per tile: natural order)
+    tile = item / WPT, part = item % WPT;
+  }
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
@@ -584,9 +592,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_mfma_kernel(const BlendBw
   __shared__ float4 s2[WAVE];     // g, b, log2(255*opacity), front position (bits)
   __shared__ uint32_t s_id[WAVE + 4];
 
-  const bool ordered = tile_order_active(a.order, (uint32_t)(a.grid_x * a.grid_y));
-  const uint32_t item = ordered ? ordered_item4(blockIdx.x, (uint32_t)(a.grid_x * a.grid_y)) : xcd_remap_b(blockIdx.x, gridDim.x);
-  const uint32_t tile = (ordered ? a.order[item >> 2] : item >> 2), part = item & 3;
+  const int omode = tile_order_mode(a.order);
+  const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+  const uint32_t item = omode ? ordered_item4(blockIdx.x, n_slots) : (blockIdx.x < n_slots * 4u ? xcd_remap_b(blockIdx.x, n_slots * 4u) : n_slots * 4u);
+  const uint32_t tile = tile_of_slot(a.order, omode, item >> 2, n_slots), part = item & 3;
+  if (tile == ORDER_NO_TILE) return;
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
@@ -818,9 +828,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
   extern __shared__ __attribute__((aligned(16))) float s_dx[];  // [live channel][c = pixel & 15][q = pixel >> 4]
   static_assert(FX_BASE2 + FX_TRI2 <= WAVE * FX_LROW, "second-hop regions must fit the transposition buffer");
 
-  const bool ordered = tile_order_active(a.order, (uint32_t)(a.grid_x * a.grid_y));
-  const uint32_t item = ordered ? ordered_item4(blockIdx.x, (uint32_t)(a.grid_x * a.grid_y)) : xcd_remap_b(blockIdx.x, gridDim.x);
-  const uint32_t tile = (ordered ? a.order[item / 4] : item / 4), part = item % 4;
+  const int omode = tile_order_mode(a.order);
+  const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+  const uint32_t item = omode ? ordered_item4(blockIdx.x, n_slots) : (blockIdx.x < n_slots * 4u ? xcd_remap_b(blockIdx.x, n_slots * 4u) : n_slots * 4u);
+  const uint32_t tile = tile_of_slot(a.order, omode, item / 4, n_slots), part = item % 4;
+  if (tile == ORDER_NO_TILE) return;
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
@@ -1066,12 +1078,13 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
 int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
+  const unsigned slots = tile_slots_max(a.grid_x, a.grid_y);  // (the kernels bound themselves by the frame's own mode word)
   if (a.det_rows) {
     if (a.CE != 0) {
       set_error("deterministic backward: only the plain pass (no extra feature channels) is built");
       return GSR_EINVAL;
     }
-    hipLaunchKernelGGL((blend_backward_kernel<1, 0, 0, true>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    hipLaunchKernelGGL((blend_backward_kernel<1, 0, 0, true>), dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
   if (a.CE != 0) {
@@ -1081,32 +1094,32 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     }
     if (opt.blend_bwd_reduce == 3) {  // reductions through LDS; dynamic LDS = the image-gradient table of the live channels
       const unsigned live = 3u * (unsigned)__builtin_popcount(a.extra_mask & 0x3Fu);
-      hipLaunchKernelGGL(blend_backward_features_kernel, dim3(tiles * 4), dim3(WAVE), (live ? live : 1u) * WAVE * sizeof(float), stream, a);
+      hipLaunchKernelGGL(blend_backward_features_kernel, dim3(slots * 4), dim3(WAVE), (live ? live : 1u) * WAVE * sizeof(float), stream, a);
       return GSR_OK;
     }
-    hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
   if (opt.blend_bwd_reduce == 3 && opt.blend_bwd_waves == 4) {
-    hipLaunchKernelGGL((blend_backward_kernel<1, 3, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    hipLaunchKernelGGL((blend_backward_kernel<1, 3, 0>), dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
   if (opt.blend_bwd_reduce == 2 && opt.blend_bwd_waves == 4 && !a.loss_gt) {  // (the MFMA experiment reads its image gradients)
-    hipLaunchKernelGGL(blend_backward_mfma_kernel, dim3(tiles * 4), dim3(WAVE), 0, stream, a);
+    hipLaunchKernelGGL(blend_backward_mfma_kernel, dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
   if (opt.blend_bwd_reduce == 1) {
     switch (opt.blend_bwd_waves) {
       case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 1, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
       case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 1, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
-      default: hipLaunchKernelGGL((blend_backward_kernel<1, 1, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
+      default: hipLaunchKernelGGL((blend_backward_kernel<1, 1, 0>), dim3(slots * 4), dim3(WAVE), 0, stream, a); break;
     }
     return GSR_OK;
   }
   switch (opt.blend_bwd_waves) {
     case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 0, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 0, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
-    default: hipLaunchKernelGGL((blend_backward_kernel<1, 0, 0>), dim3(tiles * 4), dim3(WAVE), 0, stream, a); break;
+    default: hipLaunchKernelGGL((blend_backward_kernel<1, 0, 0>), dim3(slots * 4), dim3(WAVE), 0, stream, a); break;
   }
   return GSR_OK;
 }

@@ -45,12 +45,15 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
   float *s_x = s_x_all + (CE > 0 ? wv * WAVE * CE : 0);
   float4 *s0 = s0_all + wv * WAVE, *s1 = s1_all + wv * WAVE, *s2 = s2_all + wv * WAVE;
 
-  const bool ordered = tile_order_active(a.order, (uint32_t)(a.grid_x * a.grid_y));
   uint32_t tile, part;
   if constexpr (WPG == 4) {
-    const uint32_t slot = ordered ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-    tile = ordered ? a.order[slot] : slot;
+    // (the launch covers tile_slots_max() workgroups; the frame's own mode word says how many visiting slots it has)
+    const int omode = tile_order_mode(a.order);
+    const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+    const uint32_t slot = omode ? blockIdx.x : (blockIdx.x < n_slots ? xcd_remap(blockIdx.x, n_slots) : n_slots);
+    tile = tile_of_slot(a.order, omode, slot, n_slots);
     part = wv;
+    if (tile == ORDER_NO_TILE) return;  // (workgroup-uniform)
   } else {
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     tile = item / WPT, part = item % WPT;
@@ -214,18 +217,19 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
 int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
+  const unsigned slots = tile_slots_max(a.grid_x, a.grid_y);
   if (a.CE != 0) {
     if (a.CE != CE_MAX || !a.extra || !a.out_extra) {
       set_error("fused feature blend: exactly %d extra channels with input and output arrays are required", CE_MAX);
       return GSR_EINVAL;
     }
-    hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(tiles), dim3(WAVE * 4), 0, stream, a);
+    hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(slots), dim3(WAVE * 4), 0, stream, a);
     return GSR_OK;
   }
   switch (opt.blend_fwd_waves) {
     case 1: hipLaunchKernelGGL((blend_forward_kernel<4, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
     case 2: hipLaunchKernelGGL((blend_forward_kernel<2, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;
-    default: hipLaunchKernelGGL((blend_forward_kernel<1, 0>), dim3(tiles), dim3(WAVE * 4), 0, stream, a); break;
+    default: hipLaunchKernelGGL((blend_forward_kernel<1, 0>), dim3(slots), dim3(WAVE * 4), 0, stream, a); break;
   }
   return GSR_OK;
 }

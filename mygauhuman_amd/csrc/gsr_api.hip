@@ -107,7 +107,7 @@ static int set_option(Options &o, const char *key, int v) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.bucket_hist = v;
   } else if (!strcmp(key, "tile_order")) {
-    if (v != 0 && v != 1) return bad("0 (natural order) or 1 (longest lists first)");
+    if (v < 0 || v > 3) return bad("0 (natural order), 1 (longest lists first), 2 / 3 (2 x 2 / 4 x 2 tile blocks by summed length, a block per XCD)");
     o.tile_order = v;
   } else if (!strcmp(key, "tile_cull")) {
     if (v != 0 && v != 1) return bad("0 or 1");
@@ -412,7 +412,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
     if (rc != GSR_OK) return rc;
     rc = launch_tile_ranges(R, bin.keys_s, img.ranges, tiles, stream);
     if (rc != GSR_OK) return rc;
-    GSR_HIP(zero_async(img.order + tiles, sizeof(uint32_t), stream));  // natural tile order
+    GSR_HIP(zero_async(img.order, sizeof(uint32_t), stream));  // mode word 0: natural tile order
     GSR_LAUNCH_CHECK(stream, in.debug);
   }
   prof_end(PROF_BINNING, stream);

@@ -55,8 +55,9 @@ struct ImageState {
   float *final_T;       // [H*W]
   uint32_t *n_contrib;  // [H*W]
   uint2 *ranges;        // [tiles]
-  uint32_t *order;      // [tiles + 1] the order in which the blend kernels visit the tiles (long lists first), [tiles] = 1 if it
-                        // is to be used, 0 = natural order (written by every binning path)
+  uint32_t *order;      // [order_words(tiles)] the order in which the blend kernels visit the tiles: [0] = mode word written by
+                        // every binning path (0 natural order; else entries [1 ..] = tile per visiting slot, see tile_slots()),
+                        // an entry ORDER_NO_TILE = nothing to render in that slot
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -122,13 +123,44 @@ inline size_t binning_bytes(size_t R, size_t tiles) {
   binning_from_chunk(nullptr, R, tiles ? tiles : 1, &end);
   return end + 256;
 }
+// visiting order of the tiles (ImageState::order, Options::tile_order):
+//   1  tiles sorted by list length, longest first, slot k runs on XCD k % 8 (round 2)
+//   2  2 x 2 tile SUPER-BLOCKS sorted by their summed list lengths, dealt round-robin to the XCDs with the tiles of a block on ONE
+//      XCD -- neighbouring tiles share most of their Gaussians, so a record is fetched into one L2 instead of up to four
+//   3  the same with 4 x 2 blocks (eight tiles)
+// Slot layout for the block modes: block of sorted rank q occupies slots (q / 8) * 8 T + j * 8 + q % 8, j < T tiles per block:
+// slot % 8 = q % 8 = the XCD (hardware runs workgroup i on XCD i % 8 and both blend kernels keep slot % 8 = workgroup % 8).
+// Partial blocks at the image border and the last partial group of eight are padded with ORDER_NO_TILE entries.
+#if defined(__HIPCC__)
+#define GSR_HD __host__ __device__
+#else
+#define GSR_HD
+#endif
+constexpr uint32_t ORDER_NO_TILE = 0xFFFFFFFFu;
+inline size_t order_words(size_t tiles) { return 2 * tiles + 64 + 1; }
+GSR_HD inline int order_block_tiles(int mode) { return mode == 2 ? 4 : (mode == 3 ? 8 : 1); }
+// visiting slots of a tile grid under a tile_order mode (>= grid_x * grid_y); the mode a frame was binned with is only known on
+// the device (order[0]), so the blend kernels are LAUNCHED over tile_slots_max() and bound themselves by tile_slots(mode word)
+GSR_HD inline uint32_t tile_slots(int grid_x, int grid_y, int mode) {
+  const uint32_t tiles = (uint32_t)grid_x * (uint32_t)grid_y;
+  if (mode < 2) return tiles;
+  const int bx = mode == 3 ? 4 : 2, by = 2;
+  const uint32_t nsb = (uint32_t)((grid_x + bx - 1) / bx) * (uint32_t)((grid_y + by - 1) / by);
+  return (nsb + 7u) / 8u * 8u * (uint32_t)(bx * by);
+}
+inline uint32_t tile_slots_max(int grid_x, int grid_y) {
+  uint32_t m = tile_slots(grid_x, grid_y, 0);
+  for (int mode = 2; mode <= 3; mode++) m = tile_slots(grid_x, grid_y, mode) > m ? tile_slots(grid_x, grid_y, mode) : m;
+  return m;
+}
+
 inline ImageState image_from_chunk(char *chunk_, size_t npix, size_t tiles, size_t *end = nullptr) {
   ImageState s;
   uintptr_t chunk = carve_begin(chunk_);
   carve(chunk, s.final_T, npix);
   carve(chunk, s.n_contrib, npix);
   carve(chunk, s.ranges, tiles);
-  carve(chunk, s.order, tiles + 1);
+  carve(chunk, s.order, order_words(tiles));
   if (end) *end = chunk;
   return s;
 }
@@ -219,14 +251,19 @@ struct BlendFwdArgs {
   float *out_extra;    // [CE][H][W]
 };
 int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream);
-// is ImageState::order to be used (its flag word behind the last entry)?  Then the work items are NOT remapped to keep
-// neighbouring tiles on one XCD: the long lists at the front of the order must spread over all eight XCDs (hardware assigns
-// workgroup i to XCD i % 8).  With the remap they all landed on XCD 0: 377 instead of 212 us in the render() frame.
-__device__ __forceinline__ bool tile_order_active(const uint32_t *order, uint32_t n_tiles) { return order && order[n_tiles]; }
+// is ImageState::order to be used (its mode word)?  Then the work items are NOT remapped to keep neighbouring tiles on one XCD:
+// the long lists at the front of the order must spread over all eight XCDs (hardware assigns workgroup i to XCD i % 8).  With
+// the remap they all landed on XCD 0: 377 instead of 212 us in the render() frame.
+__device__ __forceinline__ int tile_order_mode(const uint32_t *order) { return order ? (int)order[0] : 0; }
+// the tile of a visiting slot (ORDER_NO_TILE: padding, or a slot beyond what this frame's mode uses)
+__device__ __forceinline__ uint32_t tile_of_slot(const uint32_t *order, int mode, uint32_t slot, uint32_t n_slots) {
+  if (slot >= n_slots) return ORDER_NO_TILE;
+  return mode ? order[1 + slot] : slot;
+}
 // ordered visiting with four waves per tile: workgroup i -> (order slot, quadrant) such that consecutive slots go to different
 // XCDs (i % 8) while the four quadrants of a slot share one (their Gaussians are fetched into one L2, not four)
-__device__ __forceinline__ uint32_t ordered_item4(uint32_t i, uint32_t n_tiles) {
-  const uint32_t full = (n_tiles / 8u) * 32u;  // workgroups of the complete groups of 8 slots x 4 quadrants
+__device__ __forceinline__ uint32_t ordered_item4(uint32_t i, uint32_t n_slots) {
+  const uint32_t full = (n_slots / 8u) * 32u;  // workgroups of the complete groups of 8 slots x 4 quadrants
   if (i >= full) return i;                     // the last, partial group: plain (slot = i / 4, quadrant = i % 4)
   const uint32_t slot = (i / 32u) * 8u + (i % 8u), part = (i / 8u) % 4u;
   return slot * 4u + part;

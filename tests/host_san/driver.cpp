@@ -281,7 +281,7 @@ static void threaded() {
     long n;
     for (int st = 0; st < 6; st++) EXPECT(gsr_profile_read(st, &ms, &n) == GSR_OK);
     if (it % 5 == 0) EXPECT(gsr_profile_reset() == GSR_OK);
-    EXPECT(gsr_set_tuning("tile_order", it & 1) == GSR_OK);
+    EXPECT(gsr_set_tuning("tile_order", it & 3) == GSR_OK);
     std::this_thread::yield();
   }
   for (auto &t : ts) t.join();

@@ -354,10 +354,13 @@ def test_deterministic_backward_and_per_stream_knobs(oracle):
             _lib.clear_stream_tuning(st)
 
 
-@pytest.mark.parametrize("P,W,H,scale", [(9000, 208, 144, 0.03), (20000, 400, 304, 0.01)])
+@pytest.mark.parametrize("P,W,H,scale", [(9000, 208, 144, 0.03), (20000, 400, 304, 0.01), (6000, 200, 56, 0.05), (3000, 17, 200, 0.1),
+                                         (500, 16, 16, 0.2)])
 def test_tile_visiting_order_does_not_change_results(P, W, H, scale):
-    """Options::tile_order (0 natural, 1 longest lists first): the blend kernels only VISIT the tiles in
-    another order (and on other XCDs); images, per-pixel state and -- with the fixed-order reduction -- gradients keep their bits."""
+    """Options::tile_order (0 natural, 1 longest lists first, 2 / 3 blocks of 2 x 2 / 4 x 2 tiles by summed length, a block per
+    XCD): the blend kernels only VISIT the tiles in another order (and on other XCDs); images, per-pixel state and -- with the
+    fixed-order reduction -- gradients keep their bits.  Ragged tile grids (odd numbers of tile rows / columns, one tile, a
+    one-tile-wide strip) exercise the padding slots of the block modes."""
     from mygauhuman_amd import _lib
     from mygauhuman_amd.diff_gaussian_rasterization import _C
     cam, g = util.make_scene(P, W, H, 13, 3, scale, 0.02)
@@ -371,7 +374,7 @@ def test_tile_visiting_order_does_not_change_results(P, W, H, scale):
     res = {}
     _lib.set_tuning("deterministic", 1)
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2, 3):
             _lib.set_tuning("tile_order", mode)
             o = _C.rasterize_gaussians(bg, T["means3D"], e, T["opacities"], T["scales"], T["rotations"], 1.0, e, cm["viewmatrix"],
                                        cm["projmatrix"], cam["tanfovx"], cam["tanfovy"], H, W, T["shs"], 3, cm["campos"], False, False)
@@ -382,11 +385,11 @@ def test_tile_visiting_order_does_not_change_results(P, W, H, scale):
                           _C.query_state("FINAL_T", P, o[0], W, H, o[5], o[6], o[7])], list(gr))
     finally:
         _lib.set_tuning("deterministic", 0)
-        _lib.set_tuning("tile_order", 1)
-    for mode in (1,):
+        _lib.set_tuning("tile_order", _lib.DEFAULT_TILE_ORDER)
+    for mode in (1, 2, 3):
         for a, b in zip(res[0][0], res[mode][0]):
-            assert torch.equal(a, b)
+            assert torch.equal(a, b), mode
         for a, b in zip(res[0][1], res[mode][1]):
-            assert torch.equal(a, b)
+            assert torch.equal(a, b), mode
     with pytest.raises(_lib.GsrError):
-        _lib.set_tuning("tile_order", 2)
+        _lib.set_tuning("tile_order", 4)

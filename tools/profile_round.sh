@@ -3,11 +3,11 @@
 # Collects, for the default bench command: the rocprofv3 kernel-trace stats, and separate PMC passes for HBM traffic
 # (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950) and wave / VALU activity.  Output: gpurun_out/<tag>_*.
 set -o pipefail
-tag=$1
+tag=$1; shift   # remaining arguments go to bench.py (e.g. --tune tile_order=2)
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python $root/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra > $out/${tag}_stats.log 2>&1 && echo "stats ok" &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_fetch -- python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $out/${tag}_pmc_fetch.log 2>&1 && echo "fetch ok" &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_write -- python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $out/${tag}_pmc_write.log 2>&1 && echo "write ok" &&
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $out/${tag}_pmc_sq -- python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $out/${tag}_pmc_sq.log 2>&1 && echo "sq ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python $root/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra "$@" > $out/${tag}_stats.log 2>&1 && echo "stats ok" &&
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_fetch -- python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra "$@" > $out/${tag}_pmc_fetch.log 2>&1 && echo "fetch ok" &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_write -- python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra "$@" > $out/${tag}_pmc_write.log 2>&1 && echo "write ok" &&
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $out/${tag}_pmc_sq -- python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra "$@" > $out/${tag}_pmc_sq.log 2>&1 && echo "sq ok"
