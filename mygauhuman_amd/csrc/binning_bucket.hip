@@ -335,7 +335,11 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     }
     return;
   }
-  const uint32_t *row = table + (size_t)blockIdx.x * tiles;
+  // the LAST workgroup of the launch owns no instances: it only builds the visiting order of the tiles (below), concurrently with
+  // the scatter of the others -- inside the last scatter workgroup that build sat on the critical path (+2 .. +5 us per frame)
+  const bool builder = blockIdx.x == gridDim.x - 1;
+  const uint32_t n_scatter = gridDim.x - 1;
+  const uint32_t *row = table + (size_t)(builder ? 0u : blockIdx.x) * tiles;
   const int per = (tiles + HB - 1) / HB, t0 = (int)threadIdx.x * per;
   uint32_t cnt[PER_MAX], mine[PER_MAX], local = 0;
 #pragma unroll
@@ -343,43 +347,45 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     const int t = t0 + k;
     const bool in = k < per && t < tiles;
     cnt[k] = in ? totals[t] : 0u;
-    mine[k] = in ? row[t] : 0u;
+    mine[k] = (in && !builder) ? row[t] : 0u;
     local += cnt[k];
   }
-  const uint32_t incl_w = wave_incl_scan(local);
   const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  if (lane == WAVE - 1) s_wtot[wave] = incl_w;
-  const uint32_t i0 = wg_start[blockIdx.x], i1 = blockIdx.x + 1 < gridDim.x ? wg_start[blockIdx.x + 1] : R;
-  __syncthreads();
-  uint32_t start = incl_w - local;
-  for (int w = 0; w < wave; w++) start += s_wtot[w];
+  if (!builder) {
+    const uint32_t incl_w = wave_incl_scan(local);
+    if (lane == WAVE - 1) s_wtot[wave] = incl_w;
+    const uint32_t i0 = wg_start[blockIdx.x], i1 = blockIdx.x + 1 < n_scatter ? wg_start[blockIdx.x + 1] : R;
+    __syncthreads();
+    uint32_t start = incl_w - local;
+    for (int w = 0; w < wave; w++) start += s_wtot[w];
 #pragma unroll
-  for (int k = 0; k < PER_MAX; k++) {
-    const int t = t0 + k;
-    if (k < per && t < tiles) {
-      s_base[t] = start + mine[k];
-      // empty tiles keep (0, 0) like the reference's zero-filled ranges (CR/rasterizer_impl.cu:312)
-      if (blockIdx.x == 0) ranges[t] = cnt[k] ? make_uint2(start, start + cnt[k]) : make_uint2(0u, 0u);
-      start += cnt[k];
+    for (int k = 0; k < PER_MAX; k++) {
+      const int t = t0 + k;
+      if (k < per && t < tiles) {
+        s_base[t] = start + mine[k];
+        // empty tiles keep (0, 0) like the reference's zero-filled ranges (CR/rasterizer_impl.cu:312)
+        if (blockIdx.x == 0) ranges[t] = cnt[k] ? make_uint2(start, start + cnt[k]) : make_uint2(0u, 0u);
+        start += cnt[k];
+      }
     }
+    __syncthreads();
+    for (uint32_t inst = i0 + threadIdx.x; inst < i1; inst += HB) {
+      const uint32_t r = rank[inst];
+      if (r == CULLED_INSTANCE) continue;
+      const uint32_t gid = gids[inst];
+      const uint32_t dbits = __float_as_uint(g.recs[gid].depth);
+      bucket[s_base[r >> 16] + (r & 0xFFFFu)] = ((uint64_t)dbits << 32) | (uint64_t)gid;
+    }
+    return;
   }
-  __syncthreads();
-  for (uint32_t inst = i0 + threadIdx.x; inst < i1; inst += HB) {
-    const uint32_t r = rank[inst];
-    if (r == CULLED_INSTANCE) continue;
-    const uint32_t gid = gids[inst];
-    const uint32_t dbits = __float_as_uint(g.recs[gid].depth);
-    bucket[s_base[r >> 16] + (r & 0xFFFFu)] = ((uint64_t)dbits << 32) | (uint64_t)gid;
-  }
-  // ---- visiting order of the tiles for the blend kernels (built by the last workgroup): the tiles with the longest lists go
-  // FIRST, dealt round-robin to the eight XCDs (tile_order_active / ordered_item4 in gsr_common.h).  A wave walks its list
+  // ---- visiting order of the tiles for the blend kernels (built by the extra workgroup): the tiles with the longest lists go
+  // FIRST, dealt round-robin to the eight XCDs (tile_order_mode / ordered_item4 in gsr_common.h).  A wave walks its list
   // serially, so a blend kernel cannot end before its longest list has been walked from wherever that wave STARTED, and the
   // natural order with a contiguous band of tile rows per XCD leaves whole XCDs short of work when the scene is not uniform.
   // Measured: close-up of a body (1,480 busy tiles, lists up to 3x the mean) blend forward 212 -> 153 us, backward 419 -> 284;
   // C3 (uniform cloud, lists 150..355) forward 114 -> 103, backward 230 -> 211: the balance is worth more than keeping
   // neighbouring tiles on one L2.  (Longest first INSIDE each XCD's band of tile rows, to keep that locality: 0.440 vs
   // 0.415 ms per C3 step; the long lists merely moved to the front of the contiguous mapping: all on XCD 0, 377 vs 212 us.)
-  if (blockIdx.x != gridDim.x - 1) return;
   __shared__ uint32_t s_red[HB / WAVE][2];
   __shared__ uint32_t s_thr;
   uint32_t busy = 0, mx = 0;
@@ -393,7 +399,6 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     busy += __shfl_xor(busy, d, WAVE);
     mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
   }
-  __syncthreads();  // (s_wtot is read above by the other waves until here)
   if (lane == 0) {
     s_red[wave][0] = busy;
     s_red[wave][1] = mx;
@@ -447,8 +452,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   // back to back in that XCD's dispatch order.  Neighbouring tiles share most of their Gaussians (a splat of mean radius 13 px
   // touches 6.6 tiles at C3): with single tiles dealt round-robin a record was fetched into up to four L2s (2 x FETCH_SIZE of
   // the blend backward 78 -> 199 MB when the per-tile order came in, profiles/r2f_pmc.csv vs r2g_pmc.csv); a block keeps it in one.
-  // The per-tile totals go through LDS (s_base is free: every wave of this workgroup has left the scatter loop).
-  __syncthreads();
+  // The per-tile totals go through LDS (s_base is free: this workgroup scatters nothing).
 #pragma unroll
   for (int k = 0; k < PER_MAX; k++) {
     const int t = t0 + k;
@@ -931,7 +935,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
       GSR_LAUNCH_CHECK(stream, debug);
       return GSR_OK;
     }
-    hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
+    hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb + 1), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
                        b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order, grid_x);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
