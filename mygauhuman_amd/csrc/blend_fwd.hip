@@ -214,6 +214,194 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (knob "blend_fwd_dma" = 1, default off: parity-green and slower -- 191 vs 144 us in the render() frame, see
+// profiles/r3_fwd_dma_experiment.txt): the fused multi-feature forward (CE_MAX extra channels), software-pipelined with
+// global -> LDS DMA.
+//
+// In the render() frame blend_forward_kernel<1, 18> ran its vector ALUs only 51 % of the time with the waves in s_waitcnt half
+// of it (profiles/r2f_render_kernels.txt): every batch of 64 list entries ends with a gather of the survivors' 72-byte feature
+// rows that the blend of THAT batch has to wait for, and the registers of the 18 extra accumulators leave three waves per
+// SIMD to hide it.  Fetching the rows a batch ahead through registers costs a wave per SIMD (measured in round 2: slower).
+// gfx950 can load global memory straight into LDS (global_load_lds_dwordx4 / _dword: lane i's data lands at M0 + 16 i / 4 i,
+// masked-off lanes write nothing, an 8-byte-aligned source is fine -- tools/ubench/lds_dma_probe.hip), so here
+//   * the cull / compaction of batch b + 1 runs BEFORE the blend of batch b (the records of b + 1 were requested two batches
+//     ago and sit in registers) and the surviving lanes send their feature rows to the other half of a double-buffered LDS
+//     area -- indexed by LANE, since the DMA decides the address; a survivor's lane is kept next to its record;
+//   * the blend of batch b then runs with the rows of b + 1, the records of b + 2 and the list entries of b + 3 in flight,
+//     and one s_waitcnt vmcnt(0) at the top of the next iteration collects what has had a whole blend phase to arrive.
+// The DMA is issued through inline assembly: the compiler does not model the LDS write of the builtin (it would drop the
+// reads) and would otherwise fence every LDS read with vmcnt(0).  No wave ends with a DMA in flight (the fence precedes the
+// early exit; the last batch issues none).  Same arithmetic, same order as blend_forward_kernel<1, CE_MAX>: images keep their bits.
+__device__ __forceinline__ void lds_dma16(const void *g, uint32_t lds_base) {
+  const uint32_t b = __builtin_amdgcn_readfirstlane(lds_base);  // (wave-uniform by construction; pins it to an SGPR)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(b) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void *g, uint32_t lds_base) {
+  const uint32_t b = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(b) : "memory");
+}
+
+constexpr int FX_PLANE16 = WAVE * 16;                    // bytes of one 16-byte-per-lane plane
+constexpr int FX_BYTES = 4 * FX_PLANE16 + 2 * WAVE * 4;  // floats 0..15 of a lane's row in four planes, floats 16, 17 in two dword planes
+constexpr int HALF = WAVE / 2;
+
+// Pipeline unit = HALF a register batch (32 list entries): the records of 64 entries sit in registers (lane <-> entry), the lower
+// 32 lanes are staged, blended, then the upper 32 -- so that the LDS a wave needs stays what blend_forward_kernel<1, 18> needs
+// (7.9 KB: five waves per SIMD; the first version staged whole batches into double-buffered 64-cell areas, 15.9 KB per wave = two
+// waves per SIMD, and ran 260 instead of 145 us: occupancy hides more latency here than the pipelining).  The DMA cell of a
+// survivor is its LANE, and the two halves of a batch use the two halves of the 64 cells: the double buffer costs no extra LDS.
+__global__ __launch_bounds__(WAVE * 4) void blend_forward_features_kernel(const BlendFwdArgs a) {
+  constexpr int CE = CE_MAX;
+  const uint32_t wv = threadIdx.x / WAVE;
+  __shared__ __attribute__((aligned(16))) char s_fx_all[4 * FX_BYTES];       // [wave]: lanes 0..31 = even half-steps, 32..63 = odd
+  __shared__ float4 s0_all[4 * WAVE], s1_all[4 * WAVE], s2_all[4 * WAVE];    // [wave][half-step parity][32 slots]
+  __shared__ uint32_t s_lane_all[4 * WAVE];
+  char *s_fx = s_fx_all + wv * FX_BYTES;
+  float4 *s0w = s0_all + wv * WAVE, *s1w = s1_all + wv * WAVE, *s2w = s2_all + wv * WAVE;
+  uint32_t *s_lanew = s_lane_all + wv * WAVE;
+  const uint32_t fx_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_fx);   // LDS byte address of this wave's area
+
+  const int omode = tile_order_mode(a.order);
+  const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+  const uint32_t slot_id = omode ? blockIdx.x : (blockIdx.x < n_slots ? xcd_remap(blockIdx.x, n_slots) : n_slots);
+  const uint32_t tile = tile_of_slot(a.order, omode, slot_id, n_slots), part = wv;
+  if (tile == ORDER_NO_TILE) return;  // (workgroup-uniform)
+  const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+  const uint32_t lane = threadIdx.x % WAVE;
+  const uint2 range = a.ranges[tile];
+  const int n = (int)(range.y - range.x);
+
+  const int px = tx * TILE + (int)(part & 1) * 8 + (int)(lane & 7);
+  const int py = ty * TILE + (int)(part >> 1) * 8 + (int)(lane >> 3);
+  const float pxf = (float)px, pyf = (float)py;
+  const bool inside = px < a.W && py < a.H;
+  float dbias = inside ? -0.02f : 1e30f;   // threshold of the alpha test: -0.02 while live, +1e30 once done
+  const int pixid = py * a.W + px;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
+  float X[CE];
+#pragma unroll
+  for (int c = 0; c < CE; c++) X[c] = 0.f;
+  uint32_t last = 0;
+  const float rx0 = (float)(tx * TILE + (int)(part & 1) * 8), rx1 = rx0 + 7.f;
+  const float ry0 = (float)(ty * TILE + (int)(part >> 1) * 8), ry1 = ry0 + 7.f;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+  // records of the register batch that is being staged (lane <-> list entry), its ids, the ids of the batch after it
+  float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+  uint32_t id_cur = 0, id_a = 0;
+  if ((int)lane < n) {
+    id_cur = a.point_list[range.x + lane];
+    const float4 *src = reinterpret_cast<const float4 *>(a.recs + id_cur);
+    p0 = src[0];
+    p1 = src[1];
+    p2 = src[2];
+  }
+  if ((int)lane + WAVE < n) id_a = a.point_list[range.x + lane + WAVE];
+
+  // stage half-step j (list entries 32 j .. 32 j + 31 = lanes 32 (j & 1) .. + 31 of the register batch): cull, compact the
+  // survivors' records into parity j & 1, send their feature rows on their way (cell = lane); after the second half of a batch
+  // request the records of the next batch.  Returns the number of survivors.
+  auto stage = [&](int j) -> int {
+    const int hp = j & 1;
+    const int idx = (j >> 1) * WAVE + (int)lane;   // list entry this lane's registers hold
+    bool keep = false;
+    if ((int)(lane >> 5) == hp && idx < n)
+      keep = (p0.x + p2.z >= rx0) && (p0.x - p2.z <= rx1) && (p0.y + p2.w >= ry0) && (p0.y - p2.w <= ry1);
+    if (keep) keep = ellipse_hits_rect(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, rx0, rx1, ry0, ry1);
+    const uint64_t kmask = __ballot(keep);
+    if (keep) {
+      const int slot = hp * HALF + __builtin_popcountll(kmask & lt);
+      constexpr float L2E = 1.4426950408889634f;
+      s0w[slot] = make_float4(p0.x, p0.y, (-0.5f * L2E) * p0.z, -L2E * p0.w);
+      s1w[slot] = make_float4((-0.5f * L2E) * p1.x, __builtin_amdgcn_logf(255.0f * p1.y), __uint_as_float((uint32_t)(idx + 1)), p1.y);
+      s2w[slot] = make_float4(p1.w, p2.x, p2.y, p1.z);
+      s_lanew[slot] = lane;
+      const float *row = a.extra + (size_t)id_cur * CE;
+#pragma unroll
+      for (int q = 0; q < 4; q++) lds_dma16(row + 4 * q, fx_base + (uint32_t)(q * FX_PLANE16));
+      lds_dma4(row + 16, fx_base + (uint32_t)(4 * FX_PLANE16));
+      lds_dma4(row + 17, fx_base + (uint32_t)(4 * FX_PLANE16 + WAVE * 4));
+    }
+    if (hp) {  // (uniform) the register batch is used up: the next batch's records and the list entries of the one after it
+      id_cur = id_a;
+      if (idx + WAVE < n) {
+        const float4 *src = reinterpret_cast<const float4 *>(a.recs + id_a);
+        p0 = src[0];
+        p1 = src[1];
+        p2 = src[2];
+      }
+      if (idx + 2 * WAVE < n) id_a = a.point_list[range.x + idx + 2 * WAVE];
+    }
+    return __builtin_popcountll(kmask);
+  };
+
+  int cnt = n > 0 ? stage(0) : 0;
+  const float4 *fx16 = reinterpret_cast<const float4 *>(s_fx);
+  const float *fx4 = reinterpret_cast<const float *>(s_fx + 4 * FX_PLANE16);
+  for (int j = 0; j * HALF < n; j++) {
+    // everything requested one blend phase ago: the feature rows of this half, the records of the next batch, list entries
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__ballot(!(dbias > 0.f)) == 0ull) break;   // every pixel of the wave is saturated (nothing is in flight here)
+    const int cnt_next = (j + 1) * HALF < n ? stage(j + 1) : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int sb = (j & 1) * HALF;
+    for (int k = 0; k < cnt; k++) {
+      const float4 g0 = s0w[sb + k];
+      const float4 g1 = s1w[sb + k];
+      const float dx = g0.x - pxf, dy = g0.y - pyf;
+      const float pw = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
+      const bool pre = !(pw > 0.0f) && ((pw + g1.y) >= dbias);
+      if (__ballot(pre) != 0ull) {
+        const float4 g2 = s2w[sb + k];
+        const uint32_t L = s_lanew[sb + k];
+        const float alpha = fminf(0.99f, g1.w * __builtin_amdgcn_exp2f(pw));
+        const bool hit = pre && !(alpha < 1.0f / 255.0f);
+        const float test_T = T * (1.0f - alpha);
+        const bool stop = hit && test_T < 0.0001f;
+        const bool blend = hit && !stop;
+        dbias = stop ? 1e30f : dbias;
+        const float w = blend ? alpha * T : 0.0f;
+        C0 += g2.x * w;
+        C1 += g2.y * w;
+        C2 += g2.z * w;
+        Dp += g2.w * w;
+        Wt += w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 f = fx16[q * WAVE + L];
+          X[4 * q + 0] += f.x * w;
+          X[4 * q + 1] += f.y * w;
+          X[4 * q + 2] += f.z * w;
+          X[4 * q + 3] += f.w * w;
+        }
+        X[16] += fx4[L] * w;
+        X[17] += fx4[WAVE + L] * w;
+        T = blend ? test_T : T;
+        last = blend ? __float_as_uint(g1.z) : last;
+      }
+    }
+    cnt = cnt_next;
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  const size_t plane = (size_t)a.H * a.W;
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  if (inside) {
+    a.final_T[pixid] = T;
+    a.n_contrib[pixid] = last;
+    a.out_color[pixid] = C0 + T * bg0;
+    a.out_color[plane + pixid] = C1 + T * bg1;
+    a.out_color[2 * plane + pixid] = C2 + T * bg2;
+    a.out_alpha[pixid] = Wt;
+    a.out_depth[pixid] = Dp;
+#pragma unroll
+    for (int c = 0; c < CE; c++) a.out_extra[(size_t)c * plane + pixid] = X[c] + T * (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2));
+  }
+}
+
 int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
@@ -223,7 +411,10 @@ int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t 
       set_error("fused feature blend: exactly %d extra channels with input and output arrays are required", CE_MAX);
       return GSR_EINVAL;
     }
-    hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(slots), dim3(WAVE * 4), 0, stream, a);
+    if (opt.blend_fwd_dma)
+      hipLaunchKernelGGL(blend_forward_features_kernel, dim3(slots), dim3(WAVE * 4), 0, stream, a);
+    else
+      hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(slots), dim3(WAVE * 4), 0, stream, a);
     return GSR_OK;
   }
   switch (opt.blend_fwd_waves) {

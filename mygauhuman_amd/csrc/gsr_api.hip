@@ -97,6 +97,9 @@ static int set_option(Options &o, const char *key, int v) {
   } else if (!strcmp(key, "blend_fwd_waves")) {
     if (v != 1 && v != 2 && v != 4) return bad("1, 2 or 4");
     o.blend_fwd_waves = v;
+  } else if (!strcmp(key, "blend_fwd_dma")) {
+    if (v != 0 && v != 1) return bad("0 or 1");
+    o.blend_fwd_dma = v;
   } else if (!strcmp(key, "blend_bwd_waves")) {
     if (v != 1 && v != 2 && v != 4) return bad("1, 2 or 4");
     o.blend_bwd_waves = v;

@@ -203,6 +203,8 @@ struct Options {
   int tile_order = 1;        // blend kernels visit the tiles longest list first, spread over the XCDs (1, default) or in the natural order (0)
   int bucket_hist = 1;       // atomics-free counting of the tile-bucket back-end (LDS histograms per workgroup); 0 = global atomics
   int bucket_cstride = 4;    // counters per 64-byte line = 16 / stride (interleaved A/B at C3, us of binning: 1: 112, 2: 106, 4: 100, 16: 126)
+  int blend_fwd_dma = 0;     // 1: fused multi-feature forward with the feature rows staged half a batch ahead by global -> LDS DMA
+                             // (parity-green experiment, SLOWER: 191 vs 144 us in the render() frame, profiles/r3_fwd_dma_experiment.txt)
   int blend_fwd_waves = 4;   // waves that cooperate on one 16x16 tile
   int blend_bwd_waves = 4;
   int blend_bwd_reduce = 3;  // 3 LDS folds (default), 0 permlane / DPP folds, 1 MFMA on folded rows, 2 transposed MFMA contraction

@@ -131,12 +131,18 @@ class AsyncCapacity:
         return int(max(cls.MIN, 64 * P, 2 * cls._dev(device if device is not None else "cuda")["largest_R"]))
 
     @classmethod
-    def watch(cls, status, capacity):
-        st = cls._dev(status.device)
-        host = st["pinned"].pop() if st["pinned"] else torch.empty(2, dtype=torch.int32).pin_memory()
-        host.copy_(status, non_blocking=True)
+    def status_words(cls, device):
+        """Two pinned host words for a forward's (R, flags): pinned memory is mapped into the device's address space, so the
+        binning kernel writes them straight to the host -- no device tensor, no copy kernel; the event of watch() tells the host
+        when they are there."""
+        st = cls._dev(device)
+        return st["pinned"].pop() if st["pinned"] else torch.zeros(2, dtype=torch.int32).pin_memory()
+
+    @classmethod
+    def watch(cls, host, capacity, device):
+        st = cls._dev(device)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(status.device))
+        ev.record(torch.cuda.current_stream(device))
         w = [host, ev, int(capacity), False, st]
         st["pending"].append(w)
         return w
@@ -239,7 +245,8 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
     geom = torch.empty((lib.gsr_geometry_bytes(P),), dtype=u8, device=dev)
     img = torch.empty((lib.gsr_image_bytes(W, H),), dtype=u8, device=dev)
     binning = torch.empty((lib.gsr_binning_bytes(cap, W, H),), dtype=u8, device=dev)
-    status = torch.empty((2,), dtype=torch.int32, device=dev)
+    # the (R, flags) words: a device tensor inside a graph capture (examined after replays), pinned host words otherwise
+    status = torch.empty((2,), dtype=torch.int32, device=dev) if capturing else AsyncCapacity.status_words(dev)
     out_extra = None
     if extra is not None:
         if tuple(extra.shape) != (P, _lib.N_EXTRA):
@@ -264,7 +271,7 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
             watch = None
             AsyncCapacity.graph_status.append(status)
         else:
-            watch = AsyncCapacity.watch(status, cap)
+            watch = AsyncCapacity.watch(status, cap, dev)
     return cap, out_color, out_depth, out_alpha, radii, geom, binning, img, out_extra, watch
 
 

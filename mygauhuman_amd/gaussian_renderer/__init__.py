@@ -28,6 +28,25 @@ from ..attributes import frame_attributes
 from ..covariance import bmm3
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
+_ZERO_POINTS = {}
+
+
+def _screenspace_leaf(xyz):
+    """The gradient holder of the 2D means (:62-66: `zeros_like(...) + 0` and retain_grad()): a zero LEAF that requires grad.  Its
+    values are never written by anybody, so every frame gets a fresh leaf over ONE shared zero buffer per (shape, dtype, device)
+    instead of a fill kernel per frame."""
+    key = (tuple(xyz.shape), xyz.dtype, str(xyz.device))
+    z = _ZERO_POINTS.get(key)
+    if z is None or (xyz.is_cuda and torch.cuda.is_current_stream_capturing() and not getattr(z, "_gsr_persistent", False)):
+        z = torch.zeros_like(xyz, requires_grad=False)
+        if not (xyz.is_cuda and torch.cuda.is_current_stream_capturing()):
+            z._gsr_persistent = True
+            if len(_ZERO_POINTS) > 16:
+                _ZERO_POINTS.clear()
+            _ZERO_POINTS[key] = z
+    return z.detach().requires_grad_(True)
+
+
 RESULT_KEYS = ("render", "render_depth", "render_alpha", "viewspace_points", "visibility_filter", "radii", "transforms",
                "translation", "correct_Rs", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis")
 
@@ -57,7 +76,7 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
     dev = pc.get_xyz.device
     # the gradient holder of the 2D means (:62-66: `zeros_like(...) + 0` and retain_grad()): a zero LEAF that requires grad
     # receives the same .grad without the extra add kernel
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev)
+    screenspace_points = _screenspace_leaf(pc.get_xyz)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

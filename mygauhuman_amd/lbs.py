@@ -56,12 +56,26 @@ class _RowGemv(torch.autograd.Function):
         return None, dv.view(ctx.vshape)
 
 
+_IDENT3 = {}
+
+
+def _ident3(dtype, device):
+    """A cached 3 x 3 identity per (dtype, device): torch.eye is a fill + a strided write every frame."""
+    key = (dtype, str(device))
+    t = _IDENT3.get(key)
+    if t is None or (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+        t = torch.eye(3, dtype=dtype, device=device)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _IDENT3[key] = t
+    return t
+
+
 def pose_offsets(smpl, rot_mats):
     """(R[1:] - I).flatten() [1,207] @ posedirs^T -> per-vertex offsets [V,3] (gaussian_model.py:805-811,827-839): one
     HBM-streaming HIP GEMV (rocBLAS needs 60 us for this 17 MB product).  No CPU / torch fallback."""
     posedirs = smpl["posedirs"]
     V = smpl["v_template"].shape[0]
-    ident = torch.eye(3, dtype=rot_mats.dtype, device=rot_mats.device)
+    ident = _ident3(rot_mats.dtype, rot_mats.device)
     feat = (rot_mats[:, 1:] - ident).reshape(rot_mats.shape[0], -1)
     pd = posedirs.reshape(V * 3, -1)
     if not (pd.is_cuda and feat.shape[0] == 1 and pd.shape[1] <= 256 and pd.dtype == torch.float32):
@@ -323,9 +337,12 @@ def coarse_deform_c2source(smpl, query_pts, params, t_params, t_vertices, lbs_we
     off_shape = _CONSTANTS.get("shape_offsets", smpl, (shapes_in,),
                                lambda: shape_offsets(smpl, shapes_in.to(query_pts.device)), smpl_keys=("shapedirs",))
     off_pose = pose_offsets(smpl, rot_mats)
-    o = lbs_deform(query_pts[0], None if normals is None else normals[0], None if lbs_weights is None else lbs_weights[0],
-                   A_big[0], A_pose[0], off_big, off_shape, off_pose, R.reshape(3, 3), Th.reshape(-1)[:3], t_vertices[0],
-                   smpl["weights"], lean=lean and not return_transl)
+    # (batch size 1: reshape, not [0] -- the backward of a select materialises a zero [1, P, 3] tensor and copies into it)
+    P_ = query_pts.shape[1]
+    o = lbs_deform(query_pts.reshape(P_, 3), None if normals is None else normals.reshape(P_, 3),
+                   None if lbs_weights is None else lbs_weights.reshape(P_, -1),
+                   A_big.reshape(24, 4, 4), A_pose.reshape(24, 4, 4), off_big, off_shape, off_pose, R.reshape(3, 3), Th.reshape(-1)[:3],
+                   t_vertices.reshape(-1, 3), smpl["weights"], lean=lean and not return_transl)
     translation = o["translation"][None] if return_transl else None
     wn = None if o["world_normals"] is None else o["world_normals"][None]
     return o["smpl_pts"][None], o["world_pts"][None], o["bweights"][None], o["transforms"][None], translation, wn
