@@ -322,6 +322,37 @@ def render_extra(dev, steps=40, warmup=30):
                             "self_check": "passed"}
     except RuntimeError as ex:   # never silent: the line says why there is no graph number
         out["one_graph"] = {"error": str(ex)[:300]}
+    # the same frame WITHOUT the bench's own loss kernels (four mean() reductions, three scalar adds, four expand / divide kernels
+    # in backward: ~100 us of torch glue that belongs to this stand-in loss, not to render()): backward is driven by the constant
+    # upstream gradients that loss would produce
+    o = render(1, cam, model, pipe, bg)
+    ups = [torch.full_like(o[k], 1.0 / o[k].numel()) for k in PHASE1_KEYS]
+    del o
+
+    def step_fixed():
+        o = render(1, cam, model, pipe, bg)
+        torch.autograd.backward([o[k] for k in PHASE1_KEYS], ups)
+        return o["render"]
+
+    def eager_fixed():
+        for p in params:
+            p.grad = None
+        step_fixed()
+    for _ in range(5):
+        eager_fixed()
+    el, per = timed(eager_fixed, steps, torch.cuda.synchronize)
+    fx = {"what": "render() forward + autograd backward from constant upstream gradients (no loss kernels)",
+          "eager": {"ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per)}}
+    try:
+        frame = GraphedFrame(step_fixed, warmup=3, zero_grads=params)
+        for _ in range(5):
+            frame.replay()
+        el, per = timed(frame.replay, steps, torch.cuda.synchronize)
+        frame.check()
+        fx["one_graph"] = {"ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per), "self_check": "passed"}
+    except RuntimeError as ex:
+        fx["one_graph"] = {"error": str(ex)[:300]}
+    out["fixed_upstream_gradient"] = fx
     return out
 
 

@@ -169,6 +169,11 @@ int gsr_rasterize_backward(int P, int D, int M, int R, const float *background, 
  * flag -- and the call leaves them zero again (the backward preprocess clears every row it consumes): no 64-byte-per-Gaussian
  * memset per backward.  Without the flag the rows are zeroed by the call, as before. */
 #define GSR_BWD_ROWS_ZEROED 2
+/* Flag for the `debug` argument of the FORWARD entry points (bit 0 = debug mode as above): the forward preprocess also zeroes the
+ * gradient accumulation rows inside geom_buffer (128 B per Gaussian, written by the thread that writes the Gaussian's record
+ * anyway), so that the backward of this frame may carry GSR_BWD_ROWS_ZEROED whatever the buffer held before -- for callers that
+ * know a backward will follow (the autograd wrappers) and allocate a fresh geometry buffer per frame. */
+#define GSR_FWD_ZERO_ROWS 2
 
 int gsr_rasterize_forward_ex(gsr_alloc_fn geometry_alloc, void *geometry_user, gsr_alloc_fn binning_alloc, void *binning_user,
                              gsr_alloc_fn image_alloc, void *image_user, int P, int D, int M, const float *background, int width,

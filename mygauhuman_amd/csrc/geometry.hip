@@ -259,6 +259,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_forward_kernel(const Pre
     dst[0] = make_float4(rec.x, rec.y, rec.conic_a, rec.conic_b);
     dst[1] = make_float4(rec.conic_c, rec.opacity, rec.depth, rec.r);
     dst[2] = make_float4(rec.g, rec.b, rec.hx, rec.hy);
+    if (a.zero_rows) {  // GSR_FWD_ZERO_ROWS: the backward that follows finds its accumulation rows zero (no fill kernel there)
+      float4 *row = reinterpret_cast<float4 *>(a.geom.grad_rows + (size_t)i * GROWX);
+#pragma unroll
+      for (int k = 0; k < GROWX / 4; k++) row[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   // block-local inclusive scan of tiles_touched (first level of the device-wide scan)
   const uint32_t incl_w = wave_incl_scan(tiles);

@@ -370,19 +370,20 @@ int forward_stage_a(const FwdIn &in, const GeomState &geom, int *radii, hipStrea
   pa.geom = geom;
   pa.prefiltered = in.prefiltered;
   pa.sh_half = in.sh_half;
+  pa.zero_rows = (in.debug & GSR_FWD_ZERO_ROWS) ? 1 : 0;
   // flag word of the prefiltered contract (see preprocess_forward_kernel); untouched and unread unless prefiltered is set
   if (in.prefiltered) GSR_HIP(zero_async(geom.total + 1, sizeof(uint32_t), stream));
   prof_begin(PROF_PREPROCESS_FWD, stream);
   int rc = launch_preprocess_forward(pa, stream);
   prof_end(PROF_PREPROCESS_FWD, stream);
   if (rc != GSR_OK) return rc;
-  GSR_LAUNCH_CHECK(stream, in.debug);
+  GSR_LAUNCH_CHECK(stream, in.debug & 1);
   if (skip_scan) return GSR_OK;  // the histogram kernel of the binning does the second scan level itself
   prof_begin(PROF_SCAN, stream);
   rc = launch_scan_block_sums(geom, in.P, stream);
   prof_end(PROF_SCAN, stream);
   if (rc != GSR_OK) return rc;
-  GSR_LAUNCH_CHECK(stream, in.debug);
+  GSR_LAUNCH_CHECK(stream, in.debug & 1);
   return GSR_OK;
 }
 
@@ -397,7 +398,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   prof_begin(PROF_BINNING, stream);
   if (R_host < 0 || opt.binning_mode == GSR_BINNING_TILE_BUCKET) {
     rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, img.order, dev_status, in.prefiltered != 0,
-                        scan_fused, opt, stream, in.debug);
+                        scan_fused, opt, stream, in.debug & 1);
     if (rc != GSR_OK) return rc;
   } else {
     const size_t R = (size_t)R_host;
@@ -410,13 +411,13 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
     uint32_t *oth_v = (passes % 2) ? bin.vals_s : bin.vals_a;
     rc = launch_duplicate(geom, radii, in.P, grid_x, grid_y, dup_k, dup_v, stream);
     if (rc != GSR_OK) return rc;
-    GSR_LAUNCH_CHECK(stream, in.debug);
-    rc = radix_sort_u64(R, dup_k, dup_v, oth_k, oth_v, dup_k, dup_v, end_bit, bin.hist, stream, in.debug);
+    GSR_LAUNCH_CHECK(stream, in.debug & 1);
+    rc = radix_sort_u64(R, dup_k, dup_v, oth_k, oth_v, dup_k, dup_v, end_bit, bin.hist, stream, in.debug & 1);
     if (rc != GSR_OK) return rc;
     rc = launch_tile_ranges(R, bin.keys_s, img.ranges, tiles, stream);
     if (rc != GSR_OK) return rc;
     GSR_HIP(zero_async(img.order, sizeof(uint32_t), stream));  // mode word 0: natural tile order
-    GSR_LAUNCH_CHECK(stream, in.debug);
+    GSR_LAUNCH_CHECK(stream, in.debug & 1);
   }
   prof_end(PROF_BINNING, stream);
 
@@ -443,7 +444,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   rc = launch_blend_forward(fa, opt, stream);
   prof_end(PROF_BLEND_FWD, stream);
   if (rc != GSR_OK) return rc;
-  GSR_LAUNCH_CHECK(stream, in.debug);
+  GSR_LAUNCH_CHECK(stream, in.debug & 1);
   return GSR_OK;
 }
 

@@ -224,6 +224,7 @@ struct PreprocessArgs {
   GeomState geom;
   int prefiltered;
   int sh_half;  // 1: shs points at IEEE half coefficients [P][16][3] (extension: fp16 SH storage), converted while staging
+  int zero_rows;  // 1: also zero the Gaussian's gradient accumulation row (GSR_FWD_ZERO_ROWS)
 };
 int launch_preprocess_forward(const PreprocessArgs &a, hipStream_t stream);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t stream);

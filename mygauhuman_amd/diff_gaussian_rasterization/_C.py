@@ -45,9 +45,13 @@ class _Scratch:
             return 0
 
 
+FWD_ZERO_ROWS = 2   # GSR_FWD_ZERO_ROWS / GSR_BWD_ROWS_ZEROED (include/gsr.h): the forward zeroes the gradient rows, the backward
+BWD_ROWS_ZEROED = 2  # of the same frame then skips its fill kernel -- `rows_zeroed=True` on the three bindings below
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, extra=None):
+                        prefiltered, debug, extra=None, rows_zeroed=False):
     """RasterizeGaussiansCUDA (DGR/rasterize_points.cu:36-120).
 
     `extra` (extension): [P, 18] float32 feature channels blended in the same pass (fused multi-feature render); the
@@ -86,7 +90,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 ptr(means3D), ptr(sh), ptr(colors), ptr(opacity), ptr(scales), float(scale_modifier), ptr(rotations),
                 ptr(cov3D_precomp), ptr(viewmatrix), ptr(projmatrix), ptr(campos), float(tan_fovx), float(tan_fovy),
                 int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
-                radii.data_ptr(), int(bool(debug)), C.byref(rendered), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
+                radii.data_ptr(), int(bool(debug)) | (FWD_ZERO_ROWS if rows_zeroed else 0), C.byref(rendered), ptr(extra),
+                0 if extra is None else _lib.N_EXTRA,
                 None if out_extra is None else out_extra.data_ptr(), sh_dtype, _stream(dev))
         for s in (geom, binning, img):
             if s.error is not None:
@@ -217,7 +222,7 @@ class AsyncCapacity:
 
 def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                               projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
-                              debug, extra=None, capacity=None):
+                              debug, extra=None, capacity=None, rows_zeroed=False):
     """Sync-free forward (extension): same inputs as rasterize_gaussians, no host read of num_rendered.
     Returns (capacity, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra | None, watch) where
     `capacity` takes the place of num_rendered in rasterize_gaussians_backward and `watch` is the deferred overflow check
@@ -231,7 +236,7 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
     if P == 0:
         out = rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                                   projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
-                                  debug, extra=extra)
+                                  debug, extra=extra, rows_zeroed=rows_zeroed)
         return (0,) + tuple(out[1:8]) + ((out[8] if extra is not None else None), None)
     capturing = torch.cuda.is_current_stream_capturing()
     if not capturing:
@@ -263,8 +268,8 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
             geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), P, int(degree), int(M), ptr(background), W, H, ptr(means3D),
             ptr(sh), ptr(colors), ptr(opacity), ptr(scales), float(scale_modifier), ptr(rotations), ptr(cov3D_precomp),
             ptr(viewmatrix), ptr(projmatrix), ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
-            out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr(), int(bool(debug)),
-            status.data_ptr(), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
+            out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr(),
+            int(bool(debug)) | (FWD_ZERO_ROWS if rows_zeroed else 0), status.data_ptr(), ptr(extra), 0 if extra is None else _lib.N_EXTRA,
             None if out_extra is None else out_extra.data_ptr(), sh_dtype, _stream(dev))
         check(rc, "gsr_rasterize_forward_async")
         if capturing:
@@ -278,7 +283,7 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,
-                                 debug, out=None, extra=None, dL_dout_extra=None):
+                                 debug, out=None, extra=None, dL_dout_extra=None, rows_zeroed=False):
     """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207).
 
     `out` (extension, keyword only in practice): dict name -> preallocated contiguous float32 tensor for any of
@@ -340,7 +345,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 ptr(dL_dout_alpha), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dsh.data_ptr() if M else None, None if dL_dscales is None else dL_dscales.data_ptr(),
-                None if dL_drotations is None else dL_drotations.data_ptr(), int(bool(debug)),
+                None if dL_drotations is None else dL_drotations.data_ptr(), int(bool(debug)) | (BWD_ROWS_ZEROED if rows_zeroed else 0),
                 ptr(extra), 0 if extra is None else _lib.N_EXTRA, None if extra is None else extra_ptrs,
                 None if dL_dextra is None else dL_dextra.data_ptr(), sh_dtype, _stream(dev))
         check(rc, "gsr_rasterize_backward")

@@ -59,8 +59,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        # (a forward autograd recorded will have a backward: let the preprocess zero the gradient rows while it is writing the
+        # Gaussian's record anyway -- the backward then needs no fill kernel)
+        ctx.rows_zeroed = any(ctx.needs_input_grad)
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
-            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump", "forward")
+            lambda *x: _C.rasterize_gaussians(*x, rows_zeroed=ctx.rows_zeroed), args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -77,7 +80,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh,
                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = _call_guarded(_C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump", "backward")
+         grad_rotations) = _call_guarded(lambda *x: _C.rasterize_gaussians_backward(*x, rows_zeroed=ctx.rows_zeroed), args, rs.debug,
+                                         "snapshot_bw.dump", "backward")
         # gradients in the order of forward()'s inputs (:146-156); raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
@@ -116,7 +120,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
                 rs.debug)
         ctx.watch = None
         if sync_free:  # no host read of num_rendered: generous capacity + deferred overflow check (_C.AsyncCapacity)
-            out = _C.rasterize_gaussians_async(*args, extra=extra)
+            out = _C.rasterize_gaussians_async(*args, extra=extra, rows_zeroed=will_backward)
             watch, out = out[9], out[:9]
             # a frame that will have a backward is examined there, before the optimizer can consume its gradients.  A frame
             # that will NOT (evaluation under no_grad, render.py-style loops) has nobody to examine a deferred flag: it waits for
@@ -127,7 +131,8 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             elif watch is not None:
                 _C.AsyncCapacity.check(watch)
         else:
-            out = _C.rasterize_gaussians(*args, extra=extra)
+            out = _C.rasterize_gaussians(*args, extra=extra, rows_zeroed=will_backward)
+        ctx.rows_zeroed = bool(will_backward)
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra = out
         ctx.set_materialize_grads(False)  # untouched images arrive as None in backward, not as zero tensors
         ctx.raster_settings = rs
@@ -155,7 +160,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
             geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, out={"lean": True}, extra=extra,
-            dL_dout_extra=list(grad_feats))
+            dL_dout_extra=list(grad_feats), rows_zeroed=ctx.rows_zeroed)
         if ctx.watch is not None:
             # the whole backward is queued; wait for the FORWARD's overflow flag only (the GPU stays busy with the backward)
             # so that an overflow raises before the optimizer consumes these gradients

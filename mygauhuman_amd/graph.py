@@ -106,9 +106,9 @@ class GraphedFrame:
             for k, (got, want) in enumerate(zip(live, eager_ref)):
                 if got is None or want is None or got.shape != want.shape:
                     continue
-                scale = float(want.abs().max())
-                err = float((got.float() - want.float()).abs().max())
-                if not (err <= rtol * scale + 1e-30) or not bool(torch.isfinite(got).all()):
+                scale = float(want.detach().abs().max())
+                err = float((got.detach().float() - want.float()).abs().max())
+                if not (err <= rtol * scale + 1e-30) or not bool(torch.isfinite(got.detach()).all()):
                     raise RuntimeError(
                         f"GraphedFrame self-check failed ({tag}, tensor {k}: max error {err:.3e} against a magnitude of {scale:.3e}): "
                         "the replayed graph does not reproduce the eager step.  On ROCm 7.2 this is what the HIP runtime's graph "

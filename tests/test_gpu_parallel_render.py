@@ -138,3 +138,25 @@ def test_bench_render_workload_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["exchange_ms"] > 0 and d["step_compute_ms"] > 0 and "REHEARSAL" in d["config"]["workload"]
     assert "_xyz" in d["config"]["leaves"] and any(k.startswith("pose_decoder.") for k in d["config"]["leaves"])
+
+
+def test_view_parallel_training_loop_keeps_replicas_identical(tmp_path):
+    """Eight iterations of the reference's training loop on two views per step (train.py:212-417): ViewParallelRender step ->
+    densification statistics -> Adam on the nine parameter groups and the two decoders, with one densify-and-prune in the middle.
+    Every rank applies the same reduced gradients and statistics and draws the same split samples, so the two replicas must hold
+    the SAME model -- bit for bit, Gaussian count included -- at the end, and the views differ per rank and per step."""
+    from mygauhuman_amd.launch import spawn_ranks
+    prefix = str(tmp_path / "vpt")
+    argv = [sys.executable, "-m", "tests.parallel_train_worker", prefix, str(P), str(V), str(W), str(H), "8", "5"]
+    codes = spawn_ranks(argv, 2, env=dict(ENV, PYTHONPATH=ROOT), timeout=900)
+    assert codes == [0, 0], codes
+    r0, r1 = (dict(np.load(f"{prefix}_rank{r}.npz")) for r in range(2))
+    assert r0["counts"][0] == P and r0["counts"][-1] != P, r0["counts"]      # the densify-and-prune really changed the model
+    np.testing.assert_array_equal(r0["counts"], r1["counts"])
+    assert not np.array_equal(r0["losses"], r1["losses"])                      # the ranks render different views
+    for k in r0:
+        if k in ("losses",):
+            continue
+        assert np.all(np.isfinite(r0[k])), k
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=f"{k}: replicas diverged")
+    assert float(r0["denom"].max()) >= 2.0   # statistics of BOTH views of a step were counted
