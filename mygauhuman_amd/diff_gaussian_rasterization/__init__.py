@@ -59,9 +59,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        # (a forward autograd recorded will have a backward: let the preprocess zero the gradient rows while it is writing the
-        # Gaussian's record anyway -- the backward then needs no fill kernel)
-        ctx.rows_zeroed = any(ctx.needs_input_grad)
+        # (GSR_FWD_ZERO_ROWS -- the forward preprocess zeroing the gradient rows so that the backward needs no fill kernel -- is
+        # built and measured SLOWER in the render() frame: preprocess forward 9.7 -> 19.2 us and backward 18.2 -> 28.7 us (it then
+        # clears the rows it consumed) against one 5 us fill kernel; the wrappers do not use it)
+        ctx.rows_zeroed = False
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
             lambda *x: _C.rasterize_gaussians(*x, rows_zeroed=ctx.rows_zeroed), args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
@@ -120,7 +121,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
                 rs.debug)
         ctx.watch = None
         if sync_free:  # no host read of num_rendered: generous capacity + deferred overflow check (_C.AsyncCapacity)
-            out = _C.rasterize_gaussians_async(*args, extra=extra, rows_zeroed=will_backward)
+            out = _C.rasterize_gaussians_async(*args, extra=extra)
             watch, out = out[9], out[:9]
             # a frame that will have a backward is examined there, before the optimizer can consume its gradients.  A frame
             # that will NOT (evaluation under no_grad, render.py-style loops) has nobody to examine a deferred flag: it waits for
@@ -131,8 +132,8 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             elif watch is not None:
                 _C.AsyncCapacity.check(watch)
         else:
-            out = _C.rasterize_gaussians(*args, extra=extra, rows_zeroed=will_backward)
-        ctx.rows_zeroed = bool(will_backward)
+            out = _C.rasterize_gaussians(*args, extra=extra)
+        ctx.rows_zeroed = False
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra = out
         ctx.set_materialize_grads(False)  # untouched images arrive as None in backward, not as zero tensors
         ctx.raster_settings = rs
