@@ -475,7 +475,8 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
             const float4 lo4 = src8[0], hi4 = src8[1];
             __builtin_amdgcn_wave_barrier();  // the next group's (r, w) stores stay behind these reads
             const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
-            if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], vsum);
+            // (a.debug_skip_atomics: measurement only -- what the kernel costs WITHOUT its gradient-row atomics)
+            if (row_live && kcol < NACC && !a.debug_skip_atomics) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + kcol], vsum);
           } else {
           qa = half8_sum(qa);
           qb = half8_sum(qb);

@@ -118,6 +118,9 @@ static int set_option(Options &o, const char *key, int v) {
   } else if (!strcmp(key, "blend_bwd_reduce")) {
     if (v < 0 || v > 3) return bad("0 (permlane / DPP folds), 1 (MFMA on folded rows), 2 (transposed MFMA contraction) or 3 (LDS folds)");
     o.blend_bwd_reduce = v;
+  } else if (!strcmp(key, "debug_no_atomics")) {
+    if (v != 0 && v != 1) return bad("0 or 1");
+    o.debug_no_atomics = v;
   } else if (!strcmp(key, "deterministic")) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.deterministic = v;
@@ -664,6 +667,7 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
     if (ba.dL_dextra_tri[t]) ba.extra_mask |= 1u << t;
   }
   ba.det_rows = det_rows;
+  ba.debug_skip_atomics = opt.debug_no_atomics;
   ba.radii = radii;
   ba.point_offsets = geom.point_offsets;
   ba.tiles_touched = geom.tiles_touched;

@@ -209,6 +209,7 @@ struct Options {
   int blend_bwd_waves = 4;
   int blend_bwd_reduce = 3;  // 3 LDS folds (default), 0 permlane / DPP folds, 1 MFMA on folded rows, 2 transposed MFMA contraction
   int deterministic = 0;     // backward: fixed-order reduction of the gradient rows instead of float atomics
+  int debug_no_atomics = 0;  // MEASUREMENT ONLY: the plain blend backward without its gradient-row atomics (gradients are wrong)
 };
 Options options_for(hipStream_t stream);
 
@@ -298,6 +299,7 @@ struct BlendBwdArgs {
   float *det_rows;             // null = atomics
   const int *radii;
   const uint32_t *point_offsets, *tiles_touched;
+  int debug_skip_atomics;      // measurement knob "debug_no_atomics" (LDS-fold plain kernel only): results are WRONG when set
 };
 int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t *tiles_touched, const float *det_rows,
                            size_t n_slots, float *grad_rows, hipStream_t stream);
