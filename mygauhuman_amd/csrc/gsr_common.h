@@ -137,7 +137,9 @@ inline size_t binning_bytes(size_t R, size_t tiles) {
 #define GSR_HD
 #endif
 constexpr uint32_t ORDER_NO_TILE = 0xFFFFFFFFu;
-inline size_t order_words(size_t tiles) { return 2 * tiles + 64 + 1; }
+// mode word + the most visiting slots any mode needs: 4 x 2 blocks on a grid one tile wide pad every block from two tiles to eight
+// ((nsb + 7) * 8 <= (gx + 3)(gy + 1) + 56 <= 4 tiles + 63)
+inline size_t order_words(size_t tiles) { return 4 * tiles + 64 + 1; }
 GSR_HD inline int order_block_tiles(int mode) { return mode == 2 ? 4 : (mode == 3 ? 8 : 1); }
 // visiting slots of a tile grid under a tile_order mode (>= grid_x * grid_y); the mode a frame was binned with is only known on
 // the device (order[0]), so the blend kernels are LAUNCHED over tile_slots_max() and bound themselves by tile_slots(mode word)

@@ -70,7 +70,8 @@ static void check_carving() {
       if (i) EXPECT(static_cast<const char *>(starts[i - 1]) + sizes[i - 1] <= s);
     }
   }
-  const int dims[][2] = {{1, 1}, {16, 16}, {17, 33}, {160, 96}, {512, 512}, {1024, 1024}, {1920, 1080}, {4096, 4096}};
+  const int dims[][2] = {{1, 1}, {16, 16}, {17, 33}, {160, 96}, {512, 512}, {1024, 1024}, {1920, 1080}, {4096, 4096},
+                         {16, 400}, {16, 16000}, {16000, 16}, {48, 7000}, {33, 33}};
   const size_t Rs[] = {0, 1, 4095, 4096, 4097, 1326873, 5000000};
   for (auto &d : dims)
     for (size_t R : Rs) {
@@ -94,7 +95,9 @@ static void check_carving() {
       EXPECT(reinterpret_cast<char *>(s.final_T + npix) <= reinterpret_cast<char *>(s.n_contrib));
       EXPECT(reinterpret_cast<char *>(s.n_contrib + npix) <= reinterpret_cast<char *>(s.ranges));
       EXPECT(reinterpret_cast<char *>(s.ranges + tiles) <= reinterpret_cast<char *>(s.order));
-      EXPECT(reinterpret_cast<char *>(s.order + tiles + 1) <= iend);
+      EXPECT(reinterpret_cast<char *>(s.order + order_words(tiles)) <= iend);
+      // every visiting-order mode fits the order array of this grid (mode word + slots)
+      for (int mode = 0; mode <= 3; mode++) EXPECT(1 + (size_t)tile_slots((d[0] + 15) / 16, (d[1] + 15) / 16, mode) <= order_words(tiles));
     }
 }
 

@@ -355,7 +355,7 @@ def test_deterministic_backward_and_per_stream_knobs(oracle):
 
 
 @pytest.mark.parametrize("P,W,H,scale", [(9000, 208, 144, 0.03), (20000, 400, 304, 0.01), (6000, 200, 56, 0.05), (3000, 17, 200, 0.1),
-                                         (500, 16, 16, 0.2)])
+                                         (500, 16, 16, 0.2), (3000, 16, 400, 0.1), (3000, 400, 16, 0.1)])
 def test_tile_visiting_order_does_not_change_results(P, W, H, scale):
     """Options::tile_order (0 natural, 1 longest lists first, 2 / 3 blocks of 2 x 2 / 4 x 2 tiles by summed length, a block per
     XCD): the blend kernels only VISIT the tiles in another order (and on other XCDs); images, per-pixel state and -- with the
