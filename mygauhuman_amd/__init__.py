@@ -14,23 +14,18 @@ import importlib
 import os
 import sys
 
-# ROCm 7.2 work-around, needed for hipGraph replays (mygauhuman_amd.graph): with the HIP runtime's AQL "graph packet capture"
-# a graph recorded over this library and torch allocations replays WRONG results once other GPU work has run between two
-# replays (measured on MI355X: profiles/r2_graph_packet_capture.txt; every replay is right with the feature off, at the same
-# replay time).  The flag is read when the HIP runtime initialises, so it has to be in the environment before the first HIP
-# call of the process -- and Python cannot tell when that was: torch.cuda.is_initialized() only tracks torch's own lazy
-# initialisation, while torch.cuda.is_available() / device_count() may already have started the runtime.  So:
-#   * bench.py, the rank launcher and tests/conftest.py export the variable before torch is imported;
-#   * importing this package sets it if nobody has (the only way a plain `import mygauhuman_amd` at the top of a script helps);
-#   * GRAPH_REPLAY_SAFE = False only records the one case that is CERTAINLY too late (torch had initialised HIP before the
-#     import and the variable was not there); True is necessary, not sufficient;
-#   * mygauhuman_amd.graph.GraphedFrame therefore verifies every captured graph once (replay, unrelated eager GPU work, replay,
-#     compare with the eager step) and raises on a mismatch instead of trusting any of the above.
-_torch = sys.modules.get("torch")
-_hip_certainly_up = bool(_torch is not None and _torch.cuda.is_initialized())
-_flag_was_set = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-GRAPH_REPLAY_SAFE = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and (_flag_was_set or not _hip_certainly_up)
+# hipGraph replays on ROCm 7.2 (mygauhuman_amd.graph): with the HIP runtime's AQL "graph packet capture" a hipMemsetAsync NODE on
+# memory of a graph's private pool replays wrong once other GPU work has run between two replays (tools/graph_bisect.py,
+# profiles/r3_graph_bisect.txt); DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 turns the feature off, at the same replay time.  The variable is
+# read when the HIP runtime starts.  This package does NOT touch the process environment on import (round 2 did: a global side effect
+# of a library import, and one Python cannot make reliable anyway -- torch.cuda.is_available() may already have started the runtime):
+#   * libgsr itself records no memset nodes (every zero-fill is a kernel), so graphs over it are right either way;
+#   * the entry points that own their process -- bench.py, the rank launcher, tests/conftest.py -- export the variable before torch
+#     is imported, because torch or another library may record memset nodes of its own inside a captured step;
+#   * mygauhuman_amd.graph.GraphedFrame VERIFIES every captured graph once (replay, unrelated eager GPU work, replay, compare with
+#     the eager step) and raises, naming the variable, if the replay is wrong.
+# GRAPH_REPLAY_SAFE only reports whether the variable was "0" when the package was imported.
+GRAPH_REPLAY_SAFE = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 
 __version__ = "0.1.0"
 

@@ -16,18 +16,17 @@ Rules of a captured region (violations bake a stale pointer or an unqueryable ob
     overflow watch out (AsyncCapacity.graph_status keeps the status tensors for check());
   * the number of Gaussians is baked in: capture again after a densification / pruning step;
   * stage profiling (gsr_profile_enable) must be off;
-  * ROCm 7.2: the HIP runtime's graph packet capture must be off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, which importing this
-    package sets if the HIP runtime is not up yet): with it, replays go wrong as soon as other GPU work runs between them.
-    Whether the flag really took effect cannot be known from Python (torch.cuda.is_available() or a device count may have
-    started the runtime before the variable was set), so a GraphedFrame VERIFIES ITSELF once after the capture: one replay,
-    unrelated eager GPU work (the condition under which the bad mode fails), a second replay, and both compared with the eager
-    warm-up step; a mismatch raises instead of handing wrong gradients to an optimizer.
+  * ROCm 7.2: under the HIP runtime's graph packet capture (the default) a memset NODE on memory of the graph's pool replays wrong
+    as soon as other GPU work runs between two replays (profiles/r3_graph_bisect.txt).  libgsr records none; torch may.  Export
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the process touches the GPU (bench.py, the rank launcher and tests/conftest.py do).
+    Whether that took effect cannot be known from Python, so a GraphedFrame VERIFIES ITSELF once after the capture: one replay,
+    unrelated eager GPU work (the condition under which the bad mode fails), a second replay, both compared with the eager
+    warm-up step; a mismatch raises -- naming the variable -- instead of handing wrong gradients to an optimizer.
 """
 import os
 
 import torch
 
-from . import GRAPH_REPLAY_SAFE
 from .diff_gaussian_rasterization import _C
 
 
@@ -50,12 +49,11 @@ class GraphedFrame:
         verify: replay twice with unrelated eager GPU work in between and compare the gradients (and the tensors step_fn returns)
         with the eager warm-up step to verify_rtol of each tensor's largest magnitude (float atomics reorder sums; the failure
         this guards against is off by many orders of magnitude); raises RuntimeError on a mismatch."""
-        # GSR_GRAPH_ALLOW_PACKET_CAPTURE=1 (experiments): capture anyway and let the self-check decide
-        allow = os.environ.get("GSR_GRAPH_ALLOW_PACKET_CAPTURE") == "1" and verify
-        if (os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" or not GRAPH_REPLAY_SAFE) and not allow:
-            raise RuntimeError("GraphedFrame: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP runtime "
-                               "starts (export it, or import mygauhuman_amd before the first torch.cuda call): on ROCm 7.2 graph "
-                               "replays over torch allocations return wrong results otherwise")
+        # Without the self-check there is nothing to stand on unless the runtime's graph packet capture is known to be off
+        if not verify and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            raise RuntimeError("GraphedFrame(verify=False): DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP "
+                               "runtime starts: on ROCm 7.2 a graph that contains a memset node on graph-pool memory (torch records "
+                               "them) replays wrong otherwise, and nothing would notice")
         self.step_fn = step_fn
         params = list(zero_grads) if zero_grads is not None else []
         side = torch.cuda.Stream()
@@ -112,7 +110,7 @@ class GraphedFrame:
                     raise RuntimeError(
                         f"GraphedFrame self-check failed ({tag}, tensor {k}: max error {err:.3e} against a magnitude of {scale:.3e}): "
                         "the replayed graph does not reproduce the eager step.  On ROCm 7.2 this is what the HIP runtime's graph "
-                        "packet capture does to graphs over torch allocations -- DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the "
+                        "packet capture does to memset nodes on graph-pool memory -- DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the "
                         "environment BEFORE the first HIP call of the process (torch.cuda.is_available() counts).")
         self.replay()
         compare("first replay")

@@ -18,14 +18,10 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-FLAG = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")  # as given by the caller; the package import below would default it to "0"
+FLAG = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")  # as given by the caller (the package import does not touch the environment)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-if FLAG is None:
-    # keep the runtime default for this process: initialise HIP BEFORE the package import can put the variable into the environment
-    torch.cuda.init()
-    torch.zeros(1, device="cuda")
 from mygauhuman_amd import _lib  # noqa: E402
 from mygauhuman_amd.diff_gaussian_rasterization import _C  # noqa: E402
 from tests import util  # noqa: E402
