@@ -40,21 +40,35 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(int R, int K, const floa
 }
 
 // dvec[k] += sum_r dout[r] * mat[r][k]   (dvec zero-initialised by the caller)
-__global__ __launch_bounds__(256) void gemv_rows_t_kernel(int R, int K, const float *mat, const float *dout, float *dvec, int rows_per_wave) {
-  const int lane = threadIdx.x % WAVE, wave = (blockIdx.x * 256 + threadIdx.x) / WAVE;
+// A fixed grid of workgroups (one per CU) strides over the rows, every wave with FOUR rows in flight (16 loads per lane); the four
+// waves' column partials meet in LDS and the workgroup issues one atomic per column.  (Round 2's version gave each wave 48
+// consecutive rows one after the other and let every wave add its 207 partials to the same 207 addresses: 82 us for this 17 MB
+// stream -- latency of 48 dependent load rounds plus 89k same-address atomics; this one: see profiles/r3c_render_kernels.txt.)
+__global__ __launch_bounds__(256) void gemv_rows_t_kernel(int R, int K, const float *mat, const float *dout, float *dvec) {
+  __shared__ float s_part[4][GEMV_KMAX];
+  const int lane = threadIdx.x % WAVE, wv = threadIdx.x / WAVE;
+  const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int r0 = wave * rows_per_wave;
-  for (int r = r0; r < min(R, r0 + rows_per_wave); r++) {
-    const float *row = mat + (size_t)r * K;
-    const float g = dout[r];
+  for (int r0 = wave * GEMV_ROWS; r0 < R; r0 += n_waves * GEMV_ROWS) {
+    float m[GEMV_ROWS][4], g[GEMV_ROWS];
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (lane + 64 * j < K) acc[j] += g * row[lane + 64 * j];
+    for (int u = 0; u < GEMV_ROWS; u++) {
+      const int r = min(r0 + u, R - 1);
+      const float *row = mat + (size_t)r * K;
+      g[u] = r0 + u < R ? dout[r] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) m[u][j] = (lane + 64 * j < K) ? row[lane + 64 * j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < GEMV_ROWS; u++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] += g[u] * m[u][j];
   }
-  if (r0 < R)
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (lane + 64 * j < K) atomicAdd(&dvec[lane + 64 * j], acc[j]);
+  for (int j = 0; j < 4; j++) s_part[wv][lane + 64 * j] = acc[j];
+  __syncthreads();
+  const int k = threadIdx.x;
+  if (k < K) atomicAdd(&dvec[k], (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k]));
 }
 
 }  // namespace gsr
@@ -84,9 +98,8 @@ int gsr_gemv_rows_t(int rows, int cols, const float *mat, const float *dout, flo
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   GSR_HIP(zero_async(dvec, sizeof(float) * cols, stream));
   if (rows == 0) return GSR_OK;
-  const int rows_per_wave = 48;
-  const int waves = (rows + rows_per_wave - 1) / rows_per_wave;
-  hipLaunchKernelGGL(gemv_rows_t_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, rows, cols, mat, dout, dvec, rows_per_wave);
+  const int groups = (rows + 4 * GEMV_ROWS - 1) / (4 * GEMV_ROWS);  // workgroups that would get one round of rows each
+  hipLaunchKernelGGL(gemv_rows_t_kernel, dim3(groups < 256 ? groups : 256), dim3(256), 0, stream, rows, cols, mat, dout, dvec);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
 }

@@ -37,18 +37,22 @@ class PoseRefiner(torch.nn.Module):
 
 
 class LbsOffsetDecoder(torch.nn.Module):
-    """xyz [1,P,3] -> skinning-weight logit offsets [1,24,P] (LBSOffsetDecoder's call surface; a 3-64-24 MLP)."""
+    """xyz [1,P,3] -> skinning-weight logit offsets [1,24,P] (LBSOffsetDecoder's call surface).  An AFFINE map of the position --
+    offsets[j] = b[j] + A[:, j] . xyz, 96 parameters, three broadcast multiply-adds -- not an MLP: the reference's network (a
+    63-d positional embedding through four 128-wide layers on every Gaussian, nets/mlp_delta_weight_lbs.py) is outside this hot
+    path, and a stand-in MLP with a 3- or 24-wide side spends the frame in rocBLAS' skinny-GEMM kernels (measured: a 3-64-24 MLP
+    on 200k points = 1.2 ms of two rocBLAS launches per frame, more than the whole render() frame)."""
 
-    def __init__(self, width=64, seed=1):
+    def __init__(self, seed=1):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
-        self.w1 = torch.nn.Parameter(torch.randn((3, width), generator=g))
-        self.b1 = torch.nn.Parameter(torch.zeros(width))
-        self.w2 = torch.nn.Parameter(0.05 * torch.randn((width, 24), generator=g) / math.sqrt(width))
+        self.A = torch.nn.Parameter(0.05 * torch.randn((3, 24), generator=g))
+        self.b = torch.nn.Parameter(torch.zeros(24))
 
     def forward(self, xyz):
-        h = torch.tanh(xyz[0] @ self.w1 + self.b1)
-        return (h @ self.w2).t()[None]
+        x = xyz[0]
+        out = self.b + x[:, 0:1] * self.A[0] + x[:, 1:2] * self.A[1] + x[:, 2:3] * self.A[2]   # [P, 24]
+        return out.t()[None]
 
 
 def body_arrays(V=6890, seed=0):
