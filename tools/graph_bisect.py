@@ -22,7 +22,6 @@ FLAG = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")  # as given by the calle
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from mygauhuman_amd import _lib  # noqa: E402
 from mygauhuman_amd.diff_gaussian_rasterization import _C  # noqa: E402
 from tests import util  # noqa: E402
 
