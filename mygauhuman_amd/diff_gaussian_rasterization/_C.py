@@ -105,6 +105,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 PREFILTER_MSG = "Point is filtered although prefiltered is set. This shouldn't happen!"  # CR/auxiliary.h:158
 
 
+class BinningCapacityExceeded(RuntimeError):
+    """A sync-free forward needed more (Gaussian, tile) instances than its binning buffer holds: that frame rendered only the
+    background.  The capacity has been raised by the time this is raised: render the frame again."""
+
+
 class AsyncCapacity:
     """Capacity policy and deferred overflow checks of the sync-free forward (rasterize_gaussians_async).
 
@@ -170,8 +175,9 @@ class AsyncCapacity:
         if flags & 2:
             raise RuntimeError("rasterize_gaussians_async: " + PREFILTER_MSG)
         if flags & 1:
-            raise RuntimeError(f"rasterize_gaussians_async: {R} (Gaussian, tile) instances exceeded the binning capacity of {w[2]}; "
-                               "that frame rendered only the background.  The capacity has been raised: render it again.")
+            raise BinningCapacityExceeded(
+                f"rasterize_gaussians_async: {R} (Gaussian, tile) instances exceeded the binning capacity of {w[2]}; "
+                "that frame rendered only the background.  The capacity has been raised: render it again.")
 
     KEEP_IN_FLIGHT = 2  # frames whose flag words may still be unread when the next forward is issued
 
@@ -210,8 +216,9 @@ class AsyncCapacity:
             if flags & 2:
                 raise RuntimeError("rasterize_gaussians_async (graph): " + PREFILTER_MSG)
             if flags & 1:
-                raise RuntimeError(f"rasterize_gaussians_async (graph): {R} instances exceeded the binning capacity baked into the graph; "
-                                   "the last replay rendered only the background -- capture again with a larger capacity")
+                raise BinningCapacityExceeded(
+                    f"rasterize_gaussians_async (graph): {R} instances exceeded the binning capacity baked into the graph; "
+                    "the last replay rendered only the background -- capture again with a larger capacity")
 
     @classmethod
     def check_all(cls):

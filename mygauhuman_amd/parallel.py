@@ -541,6 +541,7 @@ class ViewParallelRender:
         """loss_fn(out) -> scalar loss of this rank's view.  Returns (out, loss); afterwards p.grad of every leaf holds the mean
         over the ranks (reduce=True) and the statistics of the step are in .stat_grad_norm / .stat_visible / .max_radii."""
         from . import attributes
+        from .diff_gaussian_rasterization import _C as _RasterC
         from .gaussian_renderer import render
         self._examine(block_older_than=self.steps - self.max_in_flight)
         dev, b = self.device, self.bucket
@@ -554,9 +555,7 @@ class ViewParallelRender:
                 out = render(iteration, camera, self._view, self.pipe, self.bg, **render_kw)
                 loss = loss_fn(out)
                 loss.backward()
-        except RuntimeError as ex:
-            if "exceeded the binning capacity" not in str(ex):
-                raise
+        except _RasterC.BinningCapacityExceeded:
             overflowed = True   # this view rendered only the background: it contributes zeros and one count
         # ---- this rank's contribution into the flat bucket (one multi-tensor copy) + the statistics of the step
         if overflowed or out is None:
