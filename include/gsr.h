@@ -89,6 +89,10 @@ int gsr_clear_stream_tuning(gsr_stream_t stream);
  * ranges or the tile-bucket kernels), 3 blend forward, 4 blend backward, 5 backward preprocess.  stage_mask bit i
  * enables stage i; 0 disables.  gsr_profile_read returns the accumulated milliseconds and launch count of a stage. */
 int gsr_profile_enable(unsigned stage_mask);
+/* Measurement only: while a zero-filled device buffer is registered here, every wave of the blend kernels (default variants)
+ * leaves {start, end} in 100 MHz ticks + its list length: forward waves in the first half of the buffer (4 words per wave,
+ * wave index = workgroup * 4 + wave), backward waves in the second half.  words >= 2 * 16 * visiting slots; NULL switches it off. */
+int gsr_debug_wave_trace(unsigned long long *device_buffer, size_t words);
 int gsr_profile_reset(void);
 int gsr_profile_read(int stage, double *total_ms, long *launches);
 
@@ -237,6 +241,8 @@ int gsr_rasterize_backward_alpha_mask_loss(int P, int D, int M, int R, const flo
 #define GSR_Q_RANGES 10       /* uint32[tiles][2]    image */
 #define GSR_Q_FINAL_T 11      /* float[H][W]         image */
 #define GSR_Q_N_CONTRIB 12    /* uint32[H][W]        image */
+#define GSR_Q_ORDER 13        /* uint32[4 tiles + 66] image: [0] visiting mode | longest list << 8, [1] slots in use (mode 1),
+                               * [2 ..] one entry per visiting slot: tile | segment << 22 | (segments - 1) << 25 */
 int gsr_query_state(int what, int P, int R, int width, int height, const char *geom_buffer,
                     const char *binning_buffer, const char *image_buffer, void *dst, gsr_stream_t stream);
 

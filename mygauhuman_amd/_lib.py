@@ -16,7 +16,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 # every symbol include/gsr.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read",
+    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_debug_wave_trace",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
@@ -26,7 +26,7 @@ SYMBOLS = [
 
 GSR_OK = 0
 Q = dict(DEPTHS=0, MEANS2D=1, CONIC_OPACITY=2, RGB=3, COV3D=4, TILES_TOUCHED=5, POINT_OFFSETS=6, CLAMPED=7,
-         POINT_LIST=8, KEYS_SORTED=9, RANGES=10, FINAL_T=11, N_CONTRIB=12)
+         POINT_LIST=8, KEYS_SORTED=9, RANGES=10, FINAL_T=11, N_CONTRIB=12, ORDER=13)
 BINNING_GLOBAL_RADIX, BINNING_TILE_BUCKET = 0, 1
 SH_F32, SH_F16 = 0, 1  # sh_dtype of the _ex entry points
 N_EXTRA = 18  # extra feature channels of the fused multi-feature blend (six RGB triples)
@@ -34,6 +34,7 @@ DEFAULT_BINNING = BINNING_TILE_BUCKET
 DEFAULT_TILE_CULL = 1  # tuning knob "tile_cull": exact ellipse-vs-tile culling in the tile-bucket back-end
 DEFAULT_BWD_REDUCE = 3
 DEFAULT_TILE_ORDER = 1  # tuning knob "tile_order" (csrc/gsr_common.h: Options)
+DEFAULT_BLEND_LAYOUT = 0  # tuning knob "blend_layout"
 
 
 class GsrError(RuntimeError):
@@ -57,6 +58,7 @@ def _load():
     lib.gsr_clear_stream_tuning.argtypes = [C.c_void_p]
     lib.gsr_set_stream_tuning.restype = lib.gsr_clear_stream_tuning.restype = C.c_int
     lib.gsr_profile_enable.argtypes = [C.c_uint]
+    lib.gsr_debug_wave_trace.argtypes = [C.c_void_p, C.c_size_t]
     lib.gsr_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.gsr_mark_visible.argtypes = [C.c_int, fp, fp, fp, vp, vp]
     lib.gsr_rasterize_forward.argtypes = [

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
                                                                 const uint32_t *totals, const uint32_t *table, const uint32_t *rank,
                                                                 const uint32_t *gids, uint64_t *bucket, uint32_t capacity,
                                                                 uint2 *ranges, uint32_t *status, int check_prefilter, uint32_t *order, int order_mode,
-                                                                int grid_x) {
+                                                                int grid_x, uint32_t *ckpt_base, int segments) {
   constexpr int PER_MAX = (HIST_MAX_TILES + HB - 1) / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
@@ -386,29 +386,41 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   // C3 (uniform cloud, lists 150..355) forward 114 -> 103, backward 230 -> 211: the balance is worth more than keeping
   // neighbouring tiles on one L2.  (Longest first INSIDE each XCD's band of tile rows, to keep that locality: 0.440 vs
   // 0.415 ms per C3 step; the long lists merely moved to the front of the contiguous mapping: all on XCD 0, 377 vs 212 us.)
-  __shared__ uint32_t s_red[HB / WAVE][2];
-  __shared__ uint32_t s_thr;
+  __shared__ uint32_t s_red[HB / WAVE][3];
+  __shared__ uint32_t s_thr, s_busy, s_kept, s_extra, s_rec;
   uint32_t busy = 0, mx = 0;
 #pragma unroll
   for (int k = 0; k < PER_MAX; k++) {
     busy += cnt[k] ? 1u : 0u;
     mx = max(mx, cnt[k]);
   }
+  uint32_t kept = local;  // instances in the lists (after the exact tile cull: fewer than *g.total)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     busy += __shfl_xor(busy, d, WAVE);
+    kept += __shfl_xor(kept, d, WAVE);
     mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, WAVE));
   }
   if (lane == 0) {
     s_red[wave][0] = busy;
     s_red[wave][1] = mx;
+    s_red[wave][2] = kept;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t m = 0;
     for (int w = 0; w < HB / WAVE; w++) m = max(m, s_red[w][1]);
     s_thr = order_mode == 0 ? 0u : m;  // Options::tile_order: 0 natural order; the longest list (0: nothing to render)
-    order[0] = s_thr ? (uint32_t)order_mode : 0u;
+    order[0] = s_thr ? ((uint32_t)order_mode | (min(m, 0xFFFFFFu) << 8)) : 0u;
+    uint32_t b = 0, kp = 0;
+    for (int w = 0; w < HB / WAVE; w++) {
+      b += s_red[w][0];
+      kp += s_red[w][2];
+    }
+    s_busy = b;
+    s_kept = kp;
+    s_extra = 0u;
+    s_rec = 0u;
   }
   __syncthreads();
   const uint32_t mxn = s_thr;  // the longest list, 0: natural order (or nothing to render)
@@ -420,15 +432,34 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     // counting sort of the TILES by list length, longest first: 64 length classes (class of n = 1 + 62 n / max, empty tiles
     // last), the order inside a class is whatever the LDS atomics give (every tile is rendered by itself: any order of equals
     // is as good)
+    //
+    // List segments (gsr_common.h): a list much longer than the frame's mean is cut into pieces of about the mean length, each with
+    // a visiting slot of its own (sorted by the PIECE's length) and the tile's checkpoint records reserved here.  "Much longer" =
+    // at least 1.5 x max(mean over the busy tiles, 256): a uniform cloud (C3: lists 150..355) cuts nothing.
     __syncthreads();
-    uint32_t mycls[PER_MAX];
+    const uint32_t target = max(s_busy ? s_kept / s_busy : 0u, 256u), extra_cap = seg_extra_max((uint32_t)tiles);
+    uint32_t mycls[PER_MAX], mycls0[PER_MAX], mysegs[PER_MAX];
 #pragma unroll
     for (int k = 0; k < PER_MAX; k++) {
       const int t = t0 + k;
       mycls[k] = 0u;
+      mysegs[k] = 1u;
       if (k < per && t < tiles) {
-        mycls[k] = cnt[k] == 0u ? 0u : 1u + (uint32_t)(((uint64_t)cnt[k] * (NCLS - 2)) / mxn);  // 1 .. NCLS - 1
-        atomicAdd(&s_ccount[mycls[k]], 1u);
+        const uint32_t n = cnt[k];
+        uint32_t nseg = 1u;
+        if (segments && n >= target + target / 2u) {
+          nseg = min((uint32_t)SEG_MAX, (n + target / 2u) / target);
+          if (atomicAdd(&s_extra, nseg - 1u) + (nseg - 1u) > extra_cap) nseg = 1u;  // the frame's extra slots are used up: walked whole
+        }
+        if (nseg > 1u) ckpt_base[t] = atomicAdd(&s_rec, nseg);  // (<= 2 records per extra slot: inside ckpt_records())
+        // a cut tile's FIRST slot stays in the class of the whole list -- the forward walks the list whole from that slot and must
+        // start as early as before; the other pieces are sorted by the piece's length
+        const uint32_t cost = nseg > 1u ? (uint32_t)segment_len((int)n, (int)nseg) : n;
+        mycls0[k] = n == 0u ? 0u : 1u + (uint32_t)(((uint64_t)n * (NCLS - 2)) / mxn);  // 1 .. NCLS - 1
+        mycls[k] = n == 0u ? 0u : 1u + (uint32_t)(((uint64_t)min(cost, mxn) * (NCLS - 2)) / mxn);
+        mysegs[k] = nseg;
+        atomicAdd(&s_ccount[mycls0[k]], 1u);
+        if (nseg > 1u) atomicAdd(&s_ccount[mycls[k]], nseg - 1u);
       }
     }
     __syncthreads();
@@ -438,12 +469,19 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
         s_cbase[c] = run;
         run += s_ccount[c];
       }
+      order[1] = run;  // visiting slots of this frame: tiles + extra segments
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER_MAX; k++) {
       const int t = t0 + k;
-      if (k < per && t < tiles) order[1 + atomicAdd(&s_cbase[mycls[k]], 1u)] = (uint32_t)t;
+      if (k < per && t < tiles) {
+        order[ORDER_HDR + atomicAdd(&s_cbase[mycls0[k]], 1u)] = order_entry((uint32_t)t, 0u, mysegs[k]);
+        if (mysegs[k] > 1u) {
+          const uint32_t slot = atomicAdd(&s_cbase[mycls[k]], mysegs[k] - 1u);
+          for (uint32_t sgm = 1; sgm < mysegs[k]; sgm++) order[ORDER_HDR + slot + sgm - 1u] = order_entry((uint32_t)t, sgm, mysegs[k]);
+        }
+      }
     }
     return;
   }
@@ -506,7 +544,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     const int sb = (int)threadIdx.x + k * HB;
     if (sb < nsb) {
       const uint32_t q = atomicAdd(&s_cbase[bcls[k]], 1u);  // sorted rank of this block
-      uint32_t *slot0 = order + 1 + (size_t)(q / 8u) * 8u * (uint32_t)T + (q % 8u);
+      uint32_t *slot0 = order + ORDER_HDR + (size_t)(q / 8u) * 8u * (uint32_t)T + (q % 8u);
       const int sx = (sb % nbx) * bx, sy = (sb / nbx) * by;
       for (int j = 0; j < T; j++) {
         const int tx = sx + j % bx, ty = sy + j / bx;
@@ -518,7 +556,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
   const int nsb8 = (nsb + 7) / 8 * 8;
   for (int e = nsb * T + (int)threadIdx.x; e < nsb8 * T; e += HB) {
     const int q = nsb + (e - nsb * T) / T, j = (e - nsb * T) % T;
-    order[1 + (size_t)(q / 8) * 8 * T + (size_t)j * 8 + q % 8] = ORDER_NO_TILE;
+    order[ORDER_HDR + (size_t)(q / 8) * 8 * T + (size_t)j * 8 + q % 8] = ORDER_NO_TILE;
   }
 }
 
@@ -886,8 +924,8 @@ bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity) 
 }
 
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *dev_status, bool check_prefilter, bool scan_fused,
-                   const Options &opt, hipStream_t stream, int debug) {
+                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *ckpt_base, bool segments, uint32_t *dev_status,
+                   bool check_prefilter, bool scan_fused, const Options &opt, hipStream_t stream, int debug) {
   const size_t tiles = (size_t)grid_x * grid_y;
   if (grid_x >= 1024 || grid_y >= 1024) {
     set_error("image larger than 16368 px per side is not supported by the packed tile rect");
@@ -936,7 +974,8 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
       return GSR_OK;
     }
     hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb + 1), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
-                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order, grid_x);
+                       b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order, grid_x,
+                       ckpt_base, segments ? 1 : 0);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;

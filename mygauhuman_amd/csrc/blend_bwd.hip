@@ -129,13 +129,14 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   __shared__ uint32_t s_id[WAVE + 4];
   __shared__ uint32_t s_slot[DET ? WAVE + 4 : 1];
 
-  uint32_t tile, part;
+  uint32_t tile, part, seg = 0, nseg = 1;
   if constexpr (WPT == 4) {
     const int omode = tile_order_mode(a.order);
-    const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+    const uint32_t n_slots = tile_slots_of(a.order, a.grid_x, a.grid_y, omode);
     const uint32_t item = omode ? ordered_item4(blockIdx.x, n_slots) : (blockIdx.x < n_slots * 4u ? xcd_remap_b(blockIdx.x, n_slots * 4u) : n_slots * 4u);
-    tile = tile_of_slot(a.order, omode, item / 4u, n_slots), part = item % 4u;
-    if (tile == ORDER_NO_TILE) return;  // (wave-uniform) padding slot, or beyond this frame's slots
+    const uint32_t entry = tile_of_slot(a.order, omode, item / 4u, n_slots);
+    if (entry == ORDER_NO_TILE) return;  // (wave-uniform) padding slot, or beyond this frame's slots
+    tile = order_entry_tile(entry), seg = order_entry_seg(entry), nseg = order_entry_nseg(entry), part = item % 4u;
   } else {
     const uint32_t item = xcd_remap_b(blockIdx.x, gridDim.x);  // (fewer waves per tile: natural order)
     tile = item / WPT, part = item % WPT;
@@ -144,6 +145,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
+  // this wave's SEGMENT of the list, front positions [s_lo, s_hi): the whole list unless the frame cut it (gsr_common.h "list segments")
+  const int seg_len = nseg > 1u ? segment_len(n, (int)nseg) : n;
+  const int s_lo = (int)seg * seg_len, s_hi = min(n, s_lo + seg_len);
+  if (seg != 0u && s_lo >= n) return;
+  list_priority(a.order, s_hi - s_lo, a.list_prio);
   const size_t plane = (size_t)a.H * a.W;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
@@ -202,11 +208,27 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     Tb[s] = T[s] * bgd;  // T_final * (bg . dL_dpix), over every colour channel
     X[s] = 0.f;
     maxlast = max(maxlast, lastc[s]);
+    if constexpr (SLOTS == 1) {
+      if (nseg > 1u) {  // (wave-uniform) start in the middle of the list: the forward's checkpoint at this segment's far boundary
+        const float *rb = a.ckpt + (size_t)(a.ckpt_base[tile] + seg) * (CKPT_PLANES * 256) + part * 64u + lane;
+        const float *rf = a.ckpt + (size_t)(a.ckpt_base[tile] + nseg - 1u) * (CKPT_PLANES * 256) + part * 64u + lane;
+        T[s] = inside ? rb[0] : 0.f;  // transmittance in front of entry s_hi (the final T for the last segment)
+        // what lies behind the boundary: sum_{k >= s_hi} w_k e_k = dL_dpix . (C_final - C_prefix(s_hi)), channel by channel
+        float xb = dpix0[s] * (rf[256] - rb[256]) + dpix1[s] * (rf[512] - rb[512]) + dpix2[s] * (rf[768] - rb[768]) +
+                   ddep[s] * (rf[1024] - rb[1024]) + dalp[s] * (rf[1280] - rb[1280]);
+        if (CE > 0) {
+#pragma unroll
+          for (int c = 0; c < CE; c++)
+            if ((a.extra_mask >> (c / 3)) & 1u) xb += dxp[c] * (rf[(6 + c) * 256] - rb[(6 + c) * 256]);
+        }
+        X[s] = inside ? xb : 0.f;
+      }
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) maxlast = max(maxlast, __shfl_xor(maxlast, d, WAVE));
-  // list entries at front positions >= maxlast contribute to none of this wave's pixels
-  const int skip = n - maxlast;
+  // list entries at front positions >= maxlast contribute to none of this wave's pixels; walked from the back: idx = n - 1 - position
+  const int skip = max(n - maxlast, n - s_hi), walk_end = n - s_lo;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int row = (int)(lane >> 4), kcol = (int)(lane & 15);
   // separable reduction: which gradient-row column this lane feeds in the first / second atomic instruction (0xFF = none)
@@ -237,14 +259,14 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
     __builtin_amdgcn_wave_barrier();
   }
 
-  for (int base = skip; base < n; base += WAVE) {
+  for (int base = skip; base < walk_end; base += WAVE) {
     // ---- fetch 64 entries (from the back), cull, compact into LDS in back-to-front order
     const int idx = base + (int)lane;
     bool keep = false;
     float4 r0 = make_float4(0, 0, 0, 0), r2 = make_float4(0, 0, 0, 0);
     const float4 *src = nullptr;
     uint32_t id = 0;
-    if (idx < n) {
+    if (idx < walk_end) {
       id = a.point_list[range.y - 1 - idx];
       src = reinterpret_cast<const float4 *>(a.recs + id);
       r0 = src[0];
@@ -594,14 +616,16 @@ __global__ __launch_bounds__(WAVE) void blend_backward_mfma_kernel(const BlendBw
   __shared__ uint32_t s_id[WAVE + 4];
 
   const int omode = tile_order_mode(a.order);
-  const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+  const uint32_t n_slots = tile_slots_of(a.order, a.grid_x, a.grid_y, omode);
   const uint32_t item = omode ? ordered_item4(blockIdx.x, n_slots) : (blockIdx.x < n_slots * 4u ? xcd_remap_b(blockIdx.x, n_slots * 4u) : n_slots * 4u);
-  const uint32_t tile = tile_of_slot(a.order, omode, item >> 2, n_slots), part = item & 3;
-  if (tile == ORDER_NO_TILE) return;
+  const uint32_t entry = tile_of_slot(a.order, omode, item >> 2, n_slots), part = item & 3;
+  if (entry == ORDER_NO_TILE || order_entry_seg(entry) != 0u) return;  // (this variant walks a cut list whole, from its first segment's slot)
+  const uint32_t tile = order_entry_tile(entry);
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
+  list_priority(a.order, n, a.list_prio);
   const size_t plane = (size_t)a.H * a.W;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
 
@@ -818,26 +842,37 @@ int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t 
 constexpr int FB = 32;                 // survivors staged at a time
 constexpr int FX_LROW = 12;            // floats per pixel lane in the transposition buffer (as LFOLD above)
 constexpr int FX_BASE2 = 4 * 2 * 5 * 8;  // floats of the base sums' second hop
-constexpr int FX_TRI2 = 4 * 3 * 16;      // floats of one colour triple's second hop
+constexpr int FX_TRI2 = 4 * 3 * 16;      // floats of one colour triple's second hop (two triples per pass)
+#ifndef FX_FULL_ROWS
+#define FX_FULL_ROWS false
+#endif
 
 __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const BlendBwdArgs a) {
   constexpr int CE = CE_MAX, NT = CE / 3;
   __shared__ __attribute__((aligned(16))) float s_rw[WAVE * FX_LROW];  // 768 floats: hop 1; hop 2: base [0, 320) + one triple [320, 512)
-  __shared__ __attribute__((aligned(16))) float s_x[FB * CE];
+  constexpr int XS4 = (CE + 3) / 4;  // float4s per survivor row of channel colours (18 channels: 80 bytes, whole 16-byte reads)
+  __shared__ float4 s_x[FB * XS4];
   __shared__ float4 s0[FB], s1[FB], s2[FB];
   __shared__ uint32_t s_id[FB + 4];
   extern __shared__ __attribute__((aligned(16))) float s_dx[];  // [live channel][c = pixel & 15][q = pixel >> 4]
-  static_assert(FX_BASE2 + FX_TRI2 <= WAVE * FX_LROW, "second-hop regions must fit the transposition buffer");
+  static_assert(FX_BASE2 + 2 * FX_TRI2 <= WAVE * FX_LROW, "second-hop regions must fit the transposition buffer");
+  const unsigned long long trace_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   const int omode = tile_order_mode(a.order);
-  const uint32_t n_slots = tile_slots(a.grid_x, a.grid_y, omode);
+  const uint32_t n_slots = tile_slots_of(a.order, a.grid_x, a.grid_y, omode);
   const uint32_t item = omode ? ordered_item4(blockIdx.x, n_slots) : (blockIdx.x < n_slots * 4u ? xcd_remap_b(blockIdx.x, n_slots * 4u) : n_slots * 4u);
-  const uint32_t tile = tile_of_slot(a.order, omode, item / 4, n_slots), part = item % 4;
-  if (tile == ORDER_NO_TILE) return;
+  const uint32_t entry = tile_of_slot(a.order, omode, item / 4, n_slots), part = item % 4;
+  if (entry == ORDER_NO_TILE) return;
+  const uint32_t tile = order_entry_tile(entry), seg = order_entry_seg(entry), nseg = order_entry_nseg(entry);
   const int tx = tile % a.grid_x, ty = tile / a.grid_x;
   const uint32_t lane = threadIdx.x;
   const uint2 range = a.ranges[tile];
   const int n = (int)(range.y - range.x);
+  // this wave's SEGMENT of the list, front positions [s_lo, s_hi) (gsr_common.h "list segments")
+  const int seg_len = nseg > 1u ? segment_len(n, (int)nseg) : n;
+  const int s_lo = (int)seg * seg_len, s_hi = min(n, s_lo + seg_len);
+  if (seg != 0u && s_lo >= n) return;
+  list_priority(a.order, s_hi - s_lo, a.list_prio);
   const size_t plane = (size_t)a.H * a.W;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const uint32_t mask = a.extra_mask;
@@ -857,7 +892,11 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
   float bgd = bg0 * dpix0 + bg1 * dpix1 + bg2 * dpix2;
   float dxp[CE];
   {
-    int ci = 0;  // index among the live channels (wave-uniform)
+    // table rows 0..2: the colour image's gradient (always live); then the live extra channels
+    s_dx[0 * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dpix0;
+    s_dx[1 * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dpix1;
+    s_dx[2 * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dpix2;
+    int ci = 3;  // index among the table rows (wave-uniform)
 #pragma unroll
     for (int c = 0; c < CE; c++) {
       const bool on = (mask >> (c / 3)) & 1u;
@@ -871,37 +910,58 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
   }
   const float Tb = T * bgd;  // T_final * (bg . dL_dpix), over every colour channel
   float X = 0.f;
+  if (nseg > 1u) {  // (wave-uniform) start in the middle of the list: the forward's checkpoint at this segment's far boundary
+    const float *rb = a.ckpt + (size_t)(a.ckpt_base[tile] + seg) * (CKPT_PLANES * 256) + part * 64u + lane;
+    const float *rf = a.ckpt + (size_t)(a.ckpt_base[tile] + nseg - 1u) * (CKPT_PLANES * 256) + part * 64u + lane;
+    T = inside ? rb[0] : 0.f;  // transmittance in front of entry s_hi (the final T for the last segment)
+    // what lies behind the boundary: sum_{k >= s_hi} w_k e_k = dL_dpix . (C_final - C_prefix(s_hi)), channel by channel
+    float xb = dpix0 * (rf[256] - rb[256]) + dpix1 * (rf[512] - rb[512]) + dpix2 * (rf[768] - rb[768]) + ddep * (rf[1024] - rb[1024]) +
+               dalp * (rf[1280] - rb[1280]);
+#pragma unroll
+    for (int c = 0; c < CE; c++)
+      if ((mask >> (c / 3)) & 1u) xb += dxp[c] * (rf[(6 + c) * 256] - rb[(6 + c) * 256]);
+    X = inside ? xb : 0.f;
+  }
   int maxlast = lastc;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) maxlast = max(maxlast, __shfl_xor(maxlast, d, WAVE));
-  const int skip = n - maxlast;  // list entries at front positions >= maxlast contribute to none of this wave's pixels
+  // list entries at front positions >= maxlast contribute to none of this wave's pixels; walked from the back: idx = n - 1 - position
+  const int skip = max(n - maxlast, n - s_hi), walk_end = n - s_lo;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int row = (int)(lane >> 4), kcol = (int)(lane & 15);
   const bool upper = (lane & 8u) != 0;
   const int jj = (int)(lane & 7u);
-  float dps[4][3];  // dL_dpix of the four pixels (lane & 15) + 16 q this lane sums as a reader
-  s_rw[lane * 4 + 0] = dpix0;
-  s_rw[lane * 4 + 1] = dpix1;
-  s_rw[lane * 4 + 2] = dpix2;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_wave_barrier();  // (the table is complete before any reducer lane reads it)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const float4 t4 = *reinterpret_cast<const float4 *>(&s_rw[((lane & 15) + 16 * q) * 4]);
-    dps[q][0] = t4.x;
-    dps[q][1] = t4.y;
-    dps[q][2] = t4.z;
-  }
-  __builtin_amdgcn_wave_barrier();
 
-  for (int base = skip; base < n; base += WAVE) {
+  // FULL_ROWS: the whole row (cut-off test, colour, 18 channels = 32 registers) is fetched a survivor ahead: no exposed LDS round
+  // trip, 160 VGPRs = three waves per SIMD.  Otherwise only the cut-off rows travel ahead and a contributing survivor fetches its
+  // colour + channel rows in ONE round trip: ~128 VGPRs = four waves per SIMD.
+  constexpr bool FULL_ROWS = FX_FULL_ROWS;
+  struct Row {
+    float4 g0, g1, g2;
+    float4 x[XS4];
+    int k;
+  };
+  auto fetch_rest = [&](Row &r) {
+    r.g2 = s2[r.k];
+#pragma unroll
+    for (int c = 0; c < XS4; c++) r.x[c] = s_x[r.k * XS4 + c];
+  };
+  auto fetch = [&](Row &r, int k) {  // (a row beyond the last survivor is stale LDS: read, never used)
+    r.k = min(k, FB - 1);
+    r.g0 = s0[r.k];
+    r.g1 = s1[r.k];
+    if constexpr (FULL_ROWS) fetch_rest(r);
+  };
+  for (int base = skip; base < walk_end; base += WAVE) {
     // ---- fetch 64 entries (from the back), cull; the survivors go through LDS in back-to-front order, FB at a time
     const int idx = base + (int)lane;
     bool keep = false;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
     uint32_t id = 0;
-    if (idx < n) {
+    if (idx < walk_end) {
       id = a.point_list[range.y - 1 - idx];
       const float4 *src = reinterpret_cast<const float4 *>(a.recs + id);
       r0 = src[0];
@@ -925,12 +985,18 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
         s_id[sl] = id;
         const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
 #pragma unroll
-        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[sl * CE])[q] = xs[q];
+        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[sl * XS4])[q] = xs[q];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int m = min(FB, cnt - h0);
+      // The survivors' LDS rows travel through registers ONE SURVIVOR AHEAD of the arithmetic (two register sets, A and B, used in
+      // turn: A always holds the first survivor of a group).  A wave's walk is a dependent chain and the kernel lasts as long as its
+      // slowest chains (tools/wave_trace.py): read where they are used -- the cut-off rows, then the colour row, then one read per live
+      // channel triple, each behind its own branch and its own s_waitcnt -- the rows cost four LDS round trips per survivor.
+      Row A, B;
+      fetch(A, 0);
       for (int g = 0; g < m; g += 4) {
         float accr[4], accw[4];
         uint32_t anyhit = 0;
@@ -938,38 +1004,50 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
         for (int u = 0; u < 4; u++) {
           accr[u] = 0.f;
           accw[u] = 0.f;
-          if (g + u < m) {  // wave-uniform
-            const float4 g0 = s0[g + u];
-            const float4 g1 = s1[g + u];
-            const int fpos = (int)__float_as_uint(g1.z);  // 0-based position from the front
-            const float dx = g0.x - pxf, dy = g0.y - pyf;
-            const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
-            const bool pre = (fpos < lastc) && !(p2 > 0.0f) && (p2 + g1.y >= -0.02f);
-            if (__ballot(pre) != 0ull) {  // wave-uniform: some lane may reach alpha >= 1/255
-              // select form (see blend_backward_kernel): lanes that are not hit run with alpha = G = 0, every update a no-op
-              const float4 g2 = s2[g + u];
-              const float G0 = __builtin_amdgcn_exp2f(p2);
-              const float alpha0 = fminf(0.99f, g1.w * G0);
-              const bool hit = pre && !(alpha0 < 1.0f / 255.0f);
-              const float alpha = hit ? alpha0 : 0.f, G = hit ? G0 : 0.f;
-              const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
-              const float Tn = T * rc;  // transmittance in front of this Gaussian
-              const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
-              float e = g2.x * dpix0 + g2.y * dpix1 + g2.z * dpix2 + g2.w * ddep + dalp;
+        }
+        auto one = [&](Row &r, int u) {
+          const int fpos = (int)__float_as_uint(r.g1.z);  // 0-based position from the front
+          const float dx = r.g0.x - pxf, dy = r.g0.y - pyf;
+          const float p2 = dx * (r.g0.z * dx + r.g0.w * dy) + (r.g1.x * dy) * dy;  // power * log2(e)
+          const bool pre = (fpos < lastc) && !(p2 > 0.0f) && (p2 + r.g1.y >= -0.02f);
+          if (__ballot(pre) != 0ull) {  // wave-uniform: some lane may reach alpha >= 1/255
+            if constexpr (!FULL_ROWS) fetch_rest(r);
+            // select form (see blend_backward_kernel): lanes that are not hit run with alpha = G = 0, every update a no-op
+            const float G0 = __builtin_amdgcn_exp2f(p2);
+            const float alpha0 = fminf(0.99f, r.g1.w * G0);
+            const bool hit = pre && !(alpha0 < 1.0f / 255.0f);
+            const float alpha = hit ? alpha0 : 0.f, G = hit ? G0 : 0.f;
+            const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+            const float Tn = T * rc;  // transmittance in front of this Gaussian
+            const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
+            float e = r.g2.x * dpix0 + r.g2.y * dpix1 + r.g2.z * dpix2 + r.g2.w * ddep + dalp;
+            // (every channel: dxp is zero where the image has no gradient -- twelve spare FMAs at most, no branch, no wait)
 #pragma unroll
-              for (int t = 0; t < NT; t++)
-                if ((mask >> t) & 1u) {  // wave-uniform
-#pragma unroll
-                  for (int c = 3 * t; c < 3 * t + 3; c++) e += s_x[(g + u) * CE + c] * dxp[c];
-                }
-              const float dL_dalpha = Tn * e - (X + Tb) * rc;
-              X += w * e;
-              T = Tn;
-              accr[u] = G * dL_dalpha;
-              accw[u] = w;
-              anyhit |= 1u << u;
+            for (int c = 0; c < CE; c++) {
+              const float4 v = r.x[c / 4];
+              e += (c % 4 == 0 ? v.x : (c % 4 == 1 ? v.y : (c % 4 == 2 ? v.z : v.w))) * dxp[c];
             }
+            const float dL_dalpha = Tn * e - (X + Tb) * rc;
+            X += w * e;
+            T = Tn;
+            accr[u] = G * dL_dalpha;
+            accw[u] = w;
+            anyhit |= 1u << u;
           }
+        };
+        fetch(B, g + 1);
+        one(A, 0);
+        if (g + 1 < m) {  // (wave-uniform)
+          fetch(A, g + 2);
+          one(B, 1);
+        }
+        if (g + 2 < m) {
+          fetch(B, g + 3);
+          one(A, 2);
+        }
+        if (g + 3 < m) {
+          fetch(A, g + 4);
+          one(B, 3);
         }
         if (anyhit) {  // wave-uniform
           const bool row_live = ((anyhit >> row) & 1u) && (g + row < m);
@@ -999,8 +1077,10 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
           c[1] = Dy * e0 - s1y;
           c[2] = Dy * (Dy * e0 - 2.f * s1y) + s2y;
 #pragma unroll
-          for (int ch = 0; ch < 3; ch++)
-            c[3 + ch] = (rw[0].y * dps[0][ch] + rw[1].y * dps[1][ch]) + (rw[2].y * dps[2][ch] + rw[3].y * dps[3][ch]);
+          for (int ch = 0; ch < 3; ch++) {  // (the colour image's gradient at this reader's four pixels: table rows 0..2, not 12 registers)
+            const float4 d4 = *reinterpret_cast<const float4 *>(&s_dx[ch * WAVE + (int)(lane & 15u) * 4]);
+            c[3 + ch] = (rw[0].y * d4.x + rw[1].y * d4.y) + (rw[2].y * d4.z + rw[3].y * d4.w);
+          }
           const float qa = pack_halves(c[0], c[1], upper);
           const float qb = qa * dxr;
           const float c2 = c[2] + dpp_f<0x128>(c[2]);
@@ -1013,9 +1093,20 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
           t2[16] = qc;
           t2[24] = ka;
           t2[32] = kb;
-          // ---- channel sums of the first live triple ride with the base sums' second hop; further triples take turns
-          int ci = 0;
+          // ---- channel sums: the live triples take the second hop TWO at a time (the first pair rides with the base sums)
+          int ci = 3, pend = 0;
+          uint32_t pend_t0 = 0, pend_t1 = 0;
           bool base_done = false;
+          auto base_atomic = [&]() {
+            constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;  // bit k: upper half (see blend_backward_kernel)
+            constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;   // nibble k: which of qa..kb (0..4)
+            const int k9 = kcol < 9 ? kcol : 0;
+            const int hk = (int)((HALF_OF_K >> k9) & 1u), vk = (int)((VAL_OF_K >> (4 * k9)) & 0xFu);
+            const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2 + hk) * 5 + vk) * 8]);
+            const float4 lo4 = src8[0], hi4 = src8[1];
+            const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
+            if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + kcol], vsum);
+          };
 #pragma unroll
           for (int t = 0; t < NT; t++) {
             if (!((mask >> t) & 1u)) continue;  // wave-uniform
@@ -1026,52 +1117,52 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
               x3[j] = (rw[0].y * d4.x + rw[1].y * d4.y) + (rw[2].y * d4.z + rw[3].y * d4.w);
             }
             ci += 3;
-            float *t3 = &s_rw[FX_BASE2 + (row * 3) * 16 + (int)(lane & 15u)];
+            float *t3 = &s_rw[FX_BASE2 + pend * FX_TRI2 + (row * 3) * 16 + (int)(lane & 15u)];
             t3[0] = x3[0];
             t3[16] = x3[1];
             t3[32] = x3[2];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!base_done) {
-              base_done = true;
-              constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;  // bit k: upper half (see blend_backward_kernel)
-              constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;   // nibble k: which of qa..kb (0..4)
-              const int k9 = kcol < 9 ? kcol : 0;
-              const int hk = (int)((HALF_OF_K >> k9) & 1u), vk = (int)((VAL_OF_K >> (4 * k9)) & 0xFu);
-              const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2 + hk) * 5 + vk) * 8]);
-              const float4 lo4 = src8[0], hi4 = src8[1];
-              const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
-              if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + kcol], vsum);
+            if (pend == 0) pend_t0 = (uint32_t)t;
+            else pend_t1 = (uint32_t)t;
+            pend++;
+            if (pend == 2 || (mask >> (t + 1)) == 0u) {  // (wave-uniform) a pair is complete, or this was the last live triple
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              if (!base_done) {
+                base_done = true;
+                base_atomic();
+              }
+              {  // lane (row, k < 6): column k % 3 of pending triple k / 3
+                const int which = kcol >= 3 ? 1 : 0, k3 = kcol < 6 ? kcol - 3 * which : 0;
+                const float4 *src16 = reinterpret_cast<const float4 *>(&s_rw[FX_BASE2 + which * FX_TRI2 + (row * 3 + k3) * 16]);
+                const float4 v0 = src16[0], v1 = src16[1], v2 = src16[2], v3 = src16[3];
+                const float xs = (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) +
+                                 (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
+                const uint32_t tt = which ? pend_t1 : pend_t0;
+                if (row_live && kcol < 3 * pend) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + NACC + 3 * tt + k3], xs);
+              }
+              __builtin_amdgcn_wave_barrier();  // the next pair's (or the next group's) stores stay behind these reads
+              pend = 0;
             }
-            {
-              const int k3 = kcol < 3 ? kcol : 0;
-              const float4 *src16 = reinterpret_cast<const float4 *>(&s_rw[FX_BASE2 + (row * 3 + k3) * 16]);
-              const float4 v0 = src16[0], v1 = src16[1], v2 = src16[2], v3 = src16[3];
-              const float xs = (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) +
-                               (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
-              if (row_live && kcol < 3) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + NACC + 3 * t + kcol], xs);
-            }
-            __builtin_amdgcn_wave_barrier();  // the next triple's (or the next group's) stores stay behind these reads
           }
           if (!base_done) {  // no live triple at all: the base sums' second hop alone
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;
-            constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;
-            const int k9 = kcol < 9 ? kcol : 0;
-            const int hk = (int)((HALF_OF_K >> k9) & 1u), vk = (int)((VAL_OF_K >> (4 * k9)) & 0xFu);
-            const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2 + hk) * 5 + vk) * 8]);
-            const float4 lo4 = src8[0], hi4 = src8[1];
-            const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
-            if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + kcol], vsum);
+            base_atomic();
             __builtin_amdgcn_wave_barrier();
           }
         }
       }
       __builtin_amdgcn_wave_barrier();  // keep the next half's LDS writes behind this half's reads
     }
+  }
+  if (a.trace && lane == 0) {
+    unsigned long long *r = a.trace + (size_t)blockIdx.x * 4u;
+    r[0] = trace_t0;
+    r[1] = __builtin_amdgcn_s_memrealtime();
+    r[2] = (unsigned long long)(walk_end - skip > 0 ? walk_end - skip : 0) | ((unsigned long long)n << 32);
+    r[3] = (unsigned long long)tile | ((unsigned long long)seg << 32);
   }
 }
 
@@ -1095,7 +1186,7 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     }
     if (opt.blend_bwd_reduce == 3) {  // reductions through LDS; dynamic LDS = the image-gradient table of the live channels
       const unsigned live = 3u * (unsigned)__builtin_popcount(a.extra_mask & 0x3Fu);
-      hipLaunchKernelGGL(blend_backward_features_kernel, dim3(slots * 4), dim3(WAVE), (live ? live : 1u) * WAVE * sizeof(float), stream, a);
+      hipLaunchKernelGGL(blend_backward_features_kernel, dim3(slots * 4), dim3(WAVE), (live + 3u) * WAVE * sizeof(float), stream, a);
       return GSR_OK;
     }
     hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(slots * 4), dim3(WAVE), 0, stream, a);

@@ -73,6 +73,9 @@ struct ApiState {
   // (one per calling thread at most), recycled -- not one per thread that ever called
   std::mutex pin_mutex;
   std::vector<uint32_t *> pin_free;
+  // measurement: per-wave timestamps of the blend kernels (gsr_debug_wave_trace)
+  std::atomic<unsigned long long *> trace{nullptr};
+  std::atomic<size_t> trace_words{0};
 };
 static ApiState &S() {
   static ApiState *s = new ApiState();  // intentionally leaked, see above
@@ -118,6 +121,15 @@ static int set_option(Options &o, const char *key, int v) {
   } else if (!strcmp(key, "blend_bwd_reduce")) {
     if (v < 0 || v > 3) return bad("0 (permlane / DPP folds), 1 (MFMA on folded rows), 2 (transposed MFMA contraction) or 3 (LDS folds)");
     o.blend_bwd_reduce = v;
+  } else if (!strcmp(key, "blend_layout")) {
+    if (v != 0 && v != 1) return bad("0 (quadrant waves) or 1 (4x4 blocks, four survivors per step)");
+    o.blend_layout = v;
+  } else if (!strcmp(key, "blend_segments")) {
+    if (v != 0 && v != 1) return bad("0 or 1");
+    o.blend_segments = v;
+  } else if (!strcmp(key, "blend_prio")) {
+    if (v < 0 || v > 4) return bad("0, 1 (issue priority by list length) or 2..4 (MEASUREMENT ONLY: render the longest lists alone)");
+    o.blend_prio = v;
   } else if (!strcmp(key, "debug_no_atomics")) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.debug_no_atomics = v;
@@ -252,6 +264,13 @@ int gsr_get_binning_mode(void) {
   ApiState &st = S();
   std::lock_guard<std::mutex> lock(st.opt_mutex);
   return st.default_opt.binning_mode;
+}
+
+int gsr_debug_wave_trace(unsigned long long *device_buffer, size_t words) {
+  ApiState &st = S();
+  st.trace_words.store(device_buffer ? words : 0);
+  st.trace.store(device_buffer);
+  return GSR_OK;
 }
 
 int gsr_profile_enable(unsigned stage_mask) {
@@ -400,8 +419,11 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   int rc;
   prof_begin(PROF_BINNING, stream);
   if (R_host < 0 || opt.binning_mode == GSR_BINNING_TILE_BUCKET) {
-    rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, img.order, dev_status, in.prefiltered != 0,
-                        scan_fused, opt, stream, in.debug & 1);
+    // list segments need the forward variant that writes the checkpoints (blend_forward_kernel<1, .>)
+    const bool segments = opt.blend_segments && opt.tile_order == 1 && opt.blend_layout == 0 && !opt.blend_fwd_dma &&
+                          (in.n_extra != 0 || opt.blend_fwd_waves == 4);
+    rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, img.order, img.ckpt_base, segments,
+                        dev_status, in.prefiltered != 0, scan_fused, opt, stream, in.debug & 1);
     if (rc != GSR_OK) return rc;
   } else {
     const size_t R = (size_t)R_host;
@@ -442,6 +464,14 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   fa.n_contrib = img.n_contrib;
   fa.extra = in.extra;
   fa.CE = in.n_extra;
+  fa.list_prio = opt.blend_prio;
+  fa.ckpt_base = img.ckpt_base;
+  fa.ckpt = img.ckpt;
+  {  // (first half of the trace buffer: forward waves, 4 words each; second half: backward waves)
+    ApiState &st = S();
+    const size_t need = (size_t)tile_slots_max(grid_x, grid_y) * 4u * 4u;
+    fa.trace = st.trace_words.load() / 2 >= need ? st.trace.load() : nullptr;
+  }
   fa.out_extra = in.out_extra;
   prof_begin(PROF_BLEND_FWD, stream);
   rc = launch_blend_forward(fa, opt, stream);
@@ -668,6 +698,14 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
   }
   ba.det_rows = det_rows;
   ba.debug_skip_atomics = opt.debug_no_atomics;
+  ba.list_prio = opt.blend_prio;
+  ba.ckpt_base = img.ckpt_base;
+  ba.ckpt = img.ckpt;
+  {
+    ApiState &st = S();
+    const size_t need = (size_t)tile_slots_max(ba.grid_x, ba.grid_y) * 4u * 4u;
+    ba.trace = st.trace_words.load() / 2 >= need ? st.trace.load() + st.trace_words.load() / 2 : nullptr;
+  }
   ba.radii = radii;
   ba.point_offsets = geom.point_offsets;
   ba.tiles_touched = geom.tiles_touched;
@@ -818,6 +856,7 @@ int gsr_query_state(int what, int P, int R, int width, int height, const char *g
     case GSR_Q_RANGES: src = img.ranges; bytes = tiles * 8; break;
     case GSR_Q_FINAL_T: src = img.final_T; bytes = npix * 4; break;
     case GSR_Q_N_CONTRIB: src = img.n_contrib; bytes = npix * 4; break;
+    case GSR_Q_ORDER: src = img.order; bytes = order_words(tiles) * 4; break;
     default: set_error("gsr_query_state: unknown selector %d", what); return GSR_EINVAL;
   }
   if (bytes) GSR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));

@@ -56,8 +56,10 @@ struct ImageState {
   uint32_t *n_contrib;  // [H*W]
   uint2 *ranges;        // [tiles]
   uint32_t *order;      // [order_words(tiles)] the order in which the blend kernels visit the tiles: [0] = mode word written by
-                        // every binning path (0 natural order; else entries [1 ..] = tile per visiting slot, see tile_slots()),
-                        // an entry ORDER_NO_TILE = nothing to render in that slot
+                        // every binning path (0 natural order; else entries [ORDER_HDR ..] = one per visiting slot, see tile_slots()
+                        // and order_entry_*), [1] = slots in use (mode 1); an entry ORDER_NO_TILE = nothing to render in that slot
+  uint32_t *ckpt_base;  // [tiles] first checkpoint record of a tile whose list is walked in segments (see "list segments" below)
+  float *ckpt;          // [ckpt_records(tiles)][CKPT_PLANES][256] per-pixel blend state at the segment boundaries
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -137,14 +139,41 @@ inline size_t binning_bytes(size_t R, size_t tiles) {
 #define GSR_HD
 #endif
 constexpr uint32_t ORDER_NO_TILE = 0xFFFFFFFFu;
+constexpr int ORDER_HDR = 2;  // order[0] = mode word, order[1] = visiting slots in use (mode 1), entries from order[2]
+
+// ---- list segments (mode 1 only; Options::blend_segments) ------------------------------------------------------------------
+// A wave walks its tile's list as one dependent chain, so a blend kernel lasts at least as long as its longest list takes BY ITSELF:
+// in a close-up of a body (1,480 of 4,096 tiles busy, mean list 469, longest 1,398) the backward needs 214 of its 283 us for the
+// tiles within 25 % of the longest alone (profiles/r3d_lone_wave.txt).  The backward has no early exit to respect -- final_T and
+// n_contrib are known -- so the list of an outlier tile is cut into up to four SEGMENTS walked by different waves at the same time.
+// What a segment needs to start in the middle of the list is the pixel's state at its far boundary b: the transmittance in front of
+// entry b and the colour "behind" it, sum_{k >= b} w_k (c_k . dL_dpixel) = dL_dpixel . (C_final - C_prefix(b)) for every blended
+// channel.  The FORWARD wave of such a tile therefore writes its accumulators (T, C[3], depth, weight sum, 18 extra channels) at
+// every boundary and once more at the end: the checkpoint records.  Who is cut and where is decided once per frame by the
+// workgroup that builds the visiting order (it sees every list length) and travels in the order entries, so forward and backward
+// agree by construction:  entry = tile | segment << 22 | (segments - 1) << 25.
+constexpr uint32_t ORDER_TILE_MASK = (1u << 22) - 1u;
+constexpr int SEG_MAX = 4;
+constexpr int CKPT_PLANES = 6 + CE_MAX;  // T, C0, C1, C2, depth sum, weight sum, extra channels
+GSR_HD inline uint32_t order_entry(uint32_t tile, uint32_t seg, uint32_t nseg) { return tile | (seg << 22) | ((nseg - 1u) << 25); }
+GSR_HD inline uint32_t order_entry_tile(uint32_t e) { return e & ORDER_TILE_MASK; }
+GSR_HD inline uint32_t order_entry_seg(uint32_t e) { return (e >> 22) & 7u; }
+GSR_HD inline uint32_t order_entry_nseg(uint32_t e) { return ((e >> 25) & 7u) + 1u; }
+// entries of one segment (a multiple of the 64-entry batch: the forward writes its checkpoints between batches)
+GSR_HD inline int segment_len(int n, int nseg) { return ((n + nseg - 1) / nseg + 63) & ~63; }
+// the most EXTRA visiting slots (segments beyond a tile's first) a frame may use, and the checkpoint records that go with them
+// (a tile cut into s segments takes s records: s - 1 boundaries + the final state, <= 2 per extra slot)
+GSR_HD inline uint32_t seg_extra_max(uint32_t tiles) { return tiles / 4u; }
+GSR_HD inline size_t ckpt_records(size_t tiles) { return 2 * (size_t)seg_extra_max((uint32_t)tiles); }
 // mode word + the most visiting slots any mode needs: 4 x 2 blocks on a grid one tile wide pad every block from two tiles to eight
 // ((nsb + 7) * 8 <= (gx + 3)(gy + 1) + 56 <= 4 tiles + 63)
-inline size_t order_words(size_t tiles) { return 4 * tiles + 64 + 1; }
+inline size_t order_words(size_t tiles) { return 4 * tiles + 64 + ORDER_HDR; }
 GSR_HD inline int order_block_tiles(int mode) { return mode == 2 ? 4 : (mode == 3 ? 8 : 1); }
 // visiting slots of a tile grid under a tile_order mode (>= grid_x * grid_y); the mode a frame was binned with is only known on
 // the device (order[0]), so the blend kernels are LAUNCHED over tile_slots_max() and bound themselves by tile_slots(mode word)
 GSR_HD inline uint32_t tile_slots(int grid_x, int grid_y, int mode) {
   const uint32_t tiles = (uint32_t)grid_x * (uint32_t)grid_y;
+  if (mode == 1) return tiles + seg_extra_max(tiles);  // (upper bound: the frame's own count is order[1], tile_slots_of)
   if (mode < 2) return tiles;
   const int bx = mode == 3 ? 4 : 2, by = 2;
   const uint32_t nsb = (uint32_t)((grid_x + bx - 1) / bx) * (uint32_t)((grid_y + by - 1) / by);
@@ -152,7 +181,7 @@ GSR_HD inline uint32_t tile_slots(int grid_x, int grid_y, int mode) {
 }
 inline uint32_t tile_slots_max(int grid_x, int grid_y) {
   uint32_t m = tile_slots(grid_x, grid_y, 0);
-  for (int mode = 2; mode <= 3; mode++) m = tile_slots(grid_x, grid_y, mode) > m ? tile_slots(grid_x, grid_y, mode) : m;
+  for (int mode = 1; mode <= 3; mode++) m = tile_slots(grid_x, grid_y, mode) > m ? tile_slots(grid_x, grid_y, mode) : m;
   return m;
 }
 
@@ -163,6 +192,8 @@ inline ImageState image_from_chunk(char *chunk_, size_t npix, size_t tiles, size
   carve(chunk, s.n_contrib, npix);
   carve(chunk, s.ranges, tiles);
   carve(chunk, s.order, order_words(tiles));
+  carve(chunk, s.ckpt_base, tiles);
+  carve(chunk, s.ckpt, ckpt_records(tiles) * (size_t)CKPT_PLANES * 256);
   if (end) *end = chunk;
   return s;
 }
@@ -211,6 +242,9 @@ struct Options {
   int blend_bwd_waves = 4;
   int blend_bwd_reduce = 3;  // 3 LDS folds (default), 0 permlane / DPP folds, 1 MFMA on folded rows, 2 transposed MFMA contraction
   int deterministic = 0;     // backward: fixed-order reduction of the gradient rows instead of float atomics
+  int blend_layout = 0;      // 0: a wave per 8x8 quadrant, one survivor at a time; 1: a wave per 4x4 block, four survivors per step (forward)
+  int blend_segments = 1;    // 1: the lists of outlier tiles are walked in segments by the backward (forward checkpoints), see ORDER_HDR
+  int blend_prio = 1;        // 1: blend waves take an issue priority from the length of their tile's list (list_priority)
   int debug_no_atomics = 0;  // MEASUREMENT ONLY: the plain blend backward without its gradient-row atomics (gradients are wrong)
 };
 Options options_for(hipStream_t stream);
@@ -255,16 +289,41 @@ struct BlendFwdArgs {
   const float *extra;  // [P][CE] extra feature channels blended with the same weights (null: none)
   int CE;              // 0 or CE_MAX
   float *out_extra;    // [CE][H][W]
+  int list_prio;       // Options::blend_prio
+  const uint32_t *ckpt_base;  // ImageState (null: this kernel variant writes no checkpoints -- the frame must then have no segments)
+  float *ckpt;
+  unsigned long long *trace;  // measurement (gsr_debug_wave_trace): per wave {start, end (100 MHz ticks), list length, batches walked}
 };
 int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream);
 // is ImageState::order to be used (its mode word)?  Then the work items are NOT remapped to keep neighbouring tiles on one XCD:
 // the long lists at the front of the order must spread over all eight XCDs (hardware assigns workgroup i to XCD i % 8).  With
 // the remap they all landed on XCD 0: 377 instead of 212 us in the render() frame.
-__device__ __forceinline__ int tile_order_mode(const uint32_t *order) { return order ? (int)order[0] : 0; }
-// the tile of a visiting slot (ORDER_NO_TILE: padding, or a slot beyond what this frame's mode uses)
+// (the mode word: bits 0..7 the mode, bits 8..31 the frame's longest per-tile list, clamped)
+__device__ __forceinline__ int tile_order_mode(const uint32_t *order) { return order ? (int)(order[0] & 0xFFu) : 0; }
+__device__ __forceinline__ uint32_t tile_order_longest(const uint32_t *order) { return order ? order[0] >> 8 : 0u; }
+// A blend wave's issue priority from the length of its tile's list (knob "blend_prio").  When the lists of a frame are very
+// unequal (a body: 1,480 of 4,096 tiles busy, mean list 469, longest 1,398) the kernel lasts as long as the wave with the longest
+// list, and that wave spends the first half of its life sharing its SIMD's issue slots with four short-list waves that could as well
+// run later (tools/tile_cost_census.py: the busiest slot walks 1,107 entries in ANY visiting order, the mean slot 461).  s_setprio lets
+// the instruction arbiter pick the long-list wave first whenever it has an instruction ready.
+__device__ __forceinline__ void list_priority(const uint32_t *order, int n, int enabled) {
+  const uint32_t longest = tile_order_longest(order), n4 = 4u * (uint32_t)n;
+  if (!enabled || longest == 0u) return;
+  // MEASUREMENT ONLY (knob values 2 / 3 / 4: results are WRONG): render nothing but the tiles whose list is within 25 / 50 / 75 % of the
+  // longest -- what the longest lists cost when they have the GPU to themselves (profiles/r3d_lone_wave.txt)
+  if (enabled >= 2 && n4 < (uint32_t)(enabled == 2 ? 3 : (enabled == 3 ? 2 : 1)) * longest) __builtin_amdgcn_endpgm();
+  if (n4 >= 3u * longest) __builtin_amdgcn_s_setprio(3);
+  else if (n4 >= 2u * longest) __builtin_amdgcn_s_setprio(2);
+  else if (n4 >= longest) __builtin_amdgcn_s_setprio(1);
+}
+// visiting slots of THIS frame (mode 1: tiles + the extra segments the order builder made)
+__device__ __forceinline__ uint32_t tile_slots_of(const uint32_t *order, int grid_x, int grid_y, int mode) {
+  return mode == 1 ? order[1] : tile_slots(grid_x, grid_y, mode);
+}
+// the entry of a visiting slot (ORDER_NO_TILE: padding, or a slot beyond what this frame's mode uses); see order_entry_*
 __device__ __forceinline__ uint32_t tile_of_slot(const uint32_t *order, int mode, uint32_t slot, uint32_t n_slots) {
   if (slot >= n_slots) return ORDER_NO_TILE;
-  return mode ? order[1 + slot] : slot;
+  return mode ? order[ORDER_HDR + slot] : slot;
 }
 // ordered visiting with four waves per tile: workgroup i -> (order slot, quadrant) such that consecutive slots go to different
 // XCDs (i % 8) while the four quadrants of a slot share one (their Gaussians are fetched into one L2, not four)
@@ -301,6 +360,10 @@ struct BlendBwdArgs {
   float *det_rows;             // null = atomics
   const int *radii;
   const uint32_t *point_offsets, *tiles_touched;
+  int list_prio;               // Options::blend_prio
+  const uint32_t *ckpt_base;   // ImageState: checkpoint records of the tiles the forward cut into segments
+  const float *ckpt;
+  unsigned long long *trace;   // measurement (gsr_debug_wave_trace), as BlendFwdArgs::trace
   int debug_skip_atomics;      // measurement knob "debug_no_atomics" (LDS-fold plain kernel only): results are WRONG when set
 };
 int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t *tiles_touched, const float *det_rows,
@@ -333,8 +396,8 @@ int launch_query_recs(int what, int P, const GeomState &g, void *dst, hipStream_
 // capacity = instances the binning buffer holds.  device_sized: the host does not know R; the kernels read it from
 // g.total, write dev_status[0] = R, dev_status[1] = (R > capacity) | 2 * (prefilter violation) and render nothing on overflow.
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *dev_status, bool check_prefilter, bool scan_fused,
-                   const Options &opt, hipStream_t stream, int debug);
+                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *ckpt_base, bool segments, uint32_t *dev_status,
+                   bool check_prefilter, bool scan_fused, const Options &opt, hipStream_t stream, int debug);
 // true if bucket_binning will take its atomics-free histogram path (which can also do the block-sums scan: scan_fused)
 bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity);
 

@@ -383,7 +383,7 @@ def query_state(what, P, R, W, H, geomBuffer, binningBuffer, imageBuffer):
                   RGB=((P, 3), torch.float32), COV3D=((P, 6), torch.float32), TILES_TOUCHED=((P,), torch.int32),
                   POINT_OFFSETS=((P,), torch.int32), CLAMPED=((P, 3), torch.uint8), POINT_LIST=((R,), torch.int32),
                   KEYS_SORTED=((R,), torch.int64), RANGES=((tiles, 2), torch.int32), FINAL_T=((H, W), torch.float32),
-                  N_CONTRIB=((H, W), torch.int32))
+                  N_CONTRIB=((H, W), torch.int32), ORDER=((4 * tiles + 66,), torch.int32))
     shape, dt = shapes[what]
     out = torch.zeros(shape, dtype=dt, device=dev)
     if out.numel():

@@ -95,9 +95,13 @@ static void check_carving() {
       EXPECT(reinterpret_cast<char *>(s.final_T + npix) <= reinterpret_cast<char *>(s.n_contrib));
       EXPECT(reinterpret_cast<char *>(s.n_contrib + npix) <= reinterpret_cast<char *>(s.ranges));
       EXPECT(reinterpret_cast<char *>(s.ranges + tiles) <= reinterpret_cast<char *>(s.order));
-      EXPECT(reinterpret_cast<char *>(s.order + order_words(tiles)) <= iend);
-      // every visiting-order mode fits the order array of this grid (mode word + slots)
-      for (int mode = 0; mode <= 3; mode++) EXPECT(1 + (size_t)tile_slots((d[0] + 15) / 16, (d[1] + 15) / 16, mode) <= order_words(tiles));
+      EXPECT(reinterpret_cast<char *>(s.order + order_words(tiles)) <= reinterpret_cast<char *>(s.ckpt_base));
+      EXPECT(reinterpret_cast<char *>(s.ckpt_base + tiles) <= reinterpret_cast<char *>(s.ckpt));
+      EXPECT(reinterpret_cast<char *>(s.ckpt + ckpt_records(tiles) * (size_t)CKPT_PLANES * 256) <= iend);
+      // every visiting-order mode fits the order array of this grid (header + slots), also with every extra segment slot in use
+      for (int mode = 0; mode <= 3; mode++)
+        EXPECT(ORDER_HDR + (size_t)tile_slots((d[0] + 15) / 16, (d[1] + 15) / 16, mode) <= order_words(tiles));
+      EXPECT(tile_slots_max((d[0] + 15) / 16, (d[1] + 15) / 16) >= tiles + seg_extra_max((uint32_t)tiles));
     }
 }
 

@@ -19,9 +19,18 @@ def _settings(cam, bg, deg):
         campos=util.to_dev(cam["campos"]), prefiltered=False, debug=False)
 
 
+@pytest.fixture(params=[0, 1], ids=["quadrant_waves", "block_waves_4x"])
+def layout(request):
+    """Options::blend_layout: 0 = a wave per 8x8 quadrant, 1 = a wave per 4x4 block blending four survivors per step."""
+    from mygauhuman_amd import _lib
+    _lib.set_tuning("blend_layout", request.param)
+    yield request.param
+    _lib.set_tuning("blend_layout", _lib.DEFAULT_BLEND_LAYOUT)
+
+
 @pytest.mark.parametrize("mode", ["sh", "precomp"])
 @pytest.mark.parametrize("n_extra", [1, 6])
-def test_forward_multi_equals_separate_passes(mode, n_extra):
+def test_forward_multi_equals_separate_passes(mode, n_extra, layout):
     from mygauhuman_amd.diff_gaussian_rasterization import GaussianRasterizer
     P, W, H = 5000, 150, 100
     cam, g = util.make_scene(P, W, H, 21, 3, 0.03, 0.02)

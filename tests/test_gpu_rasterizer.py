@@ -25,18 +25,22 @@ def _bg(seed):
     return np.random.default_rng(seed + 5).uniform(0, 1, 3).astype(np.float32)
 
 
-@pytest.fixture(scope="module", params=[(1, 0), (2, 0), (4, 0), (4, 1), (2, 1), (4, 2), (4, 3)], ids=lambda p: f"waves{p[0]}red{p[1]}")
+@pytest.fixture(scope="module", params=[(1, 0, 0), (2, 0, 0), (4, 0, 0), (4, 1, 0), (2, 1, 0), (4, 2, 0), (4, 3, 0), (4, 3, 1)],
+                ids=lambda p: f"waves{p[0]}red{p[1]}" + ("sp" if p[2] else ""))
 def waves(request):
-    """(waves per tile, backward reduction: 0 = DPP rows, 1 = MFMA on folded rows, 2 = transposed MFMA contraction, 3 = LDS folds)"""
+    """(waves per tile, backward reduction: 0 = DPP rows, 1 = MFMA on folded rows, 2 = transposed MFMA contraction, 3 = LDS folds,
+    blend layout: 0 = a wave per 8x8 quadrant, 1 = a wave per 4x4 block with four survivors per step)"""
     from mygauhuman_amd import _lib
-    w, red = request.param
+    w, red, layout = request.param
     _lib.set_tuning("blend_fwd_waves", w)
     _lib.set_tuning("blend_bwd_waves", w)
     _lib.set_tuning("blend_bwd_reduce", red)
+    _lib.set_tuning("blend_layout", layout)
     yield request.param
     _lib.set_tuning("blend_fwd_waves", 4)
     _lib.set_tuning("blend_bwd_waves", 4)
     _lib.set_tuning("blend_bwd_reduce", _lib.DEFAULT_BWD_REDUCE)
+    _lib.set_tuning("blend_layout", _lib.DEFAULT_BLEND_LAYOUT)
 
 
 @pytest.fixture(scope="module", params=["radix", "bucket", "bucket_tight"])

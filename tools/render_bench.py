@@ -17,7 +17,8 @@ PHASE1_KEYS = ("render", "render_alpha", "normal", "render_axis")  # the images 
 PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], np.int64)
 
 
-def main(P=200_000, V=6890, W=1024, H=1024):
+def scene(P=200_000, V=6890, W=1024, H=1024):
+    """The body scene of this tool: (model, camera, background)."""
     rng = np.random.default_rng(0)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     vt = rng.uniform(-1, 1, (V, 3)).astype(np.float32) * np.array([0.45, 0.9, 0.15], np.float32)
@@ -39,6 +40,11 @@ def main(P=200_000, V=6890, W=1024, H=1024):
     bp = dict(poses=d(big[None]), shapes=d(np.zeros((1, 10), np.float32)), R=d(np.eye(3, dtype=np.float32)), Th=d(np.zeros((1, 3), np.float32)))
     cam = cameras.ViewCamera(cam_np, "cuda", sp, bp, d(vt))
     bg = torch.zeros(3, device="cuda")
+    return model, cam, bg
+
+
+def main(P=200_000, V=6890, W=1024, H=1024):
+    model, cam, bg = scene(P, V, W, H)
     for sep, keys in ((False, PHASE1_KEYS if os.environ.get("KEYS") == "phase1" else ALL_KEYS),) if (os.environ.get("PROFILE") or os.environ.get("ONLY")) else (((False, PHASE1_KEYS), (False, ALL_KEYS), (False, PHASE1_KEYS), (False, ALL_KEYS)) if os.environ.get("ORDER") else ((False, ALL_KEYS), (False, PHASE1_KEYS), (True, ALL_KEYS))):
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep, sync_free_raster=os.environ.get("SYNC_FREE", "1") != "0")
 

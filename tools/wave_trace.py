@@ -1,0 +1,70 @@
+"""Where does the time of the render() frame's blend kernels go?  (GPU box.)  Registers a trace buffer (gsr_debug_wave_trace), runs ONE
+eager forward + backward of the tools/render_bench.py body scene and prints, for the forward and the backward blend kernel: the kernel's
+span, how many waves were resident over time, and how a wave's duration relates to the length of its list."""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from mygauhuman_amd import _lib  # noqa: E402
+from mygauhuman_amd.gaussian_renderer import render  # noqa: E402
+
+for kv in sys.argv[1:]:
+    k, v = kv.split("=")
+    _lib.set_tuning(k, int(v))
+
+
+def report(name, rec, length_of):
+    rec = rec[rec[:, 0] > 0]
+    t0, t1 = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
+    n = length_of(rec)
+    start = t0.min()
+    span = (t1.max() - start) / 100.0  # us (100 MHz ticks)
+    dur = (t1 - t0) / 100.0
+    print(f"== {name}: {len(rec)} waves, span {span:.1f} us, sum of wave durations {dur.sum() / 1e3:.1f} ms = {dur.sum() / span:.0f} waves resident on average")
+    edges = np.linspace(0, span, 11)
+    act = [int(((t0 - start) / 100.0 <= x) & ((t1 - start) / 100.0 > x)).sum() if False else int((((t0 - start) / 100.0 <= x) & ((t1 - start) / 100.0 > x)).sum())
+           for x in (edges[:-1] + edges[1:]) / 2]
+    print("   resident waves at 5 %, 15 %, ... 95 % of the span:", act)
+    late = (t0 - start) / 100.0
+    print(f"   wave starts: 50 % by {np.percentile(late, 50):.1f} us, 90 % by {np.percentile(late, 90):.1f}, last {late.max():.1f} us")
+    order = np.argsort(-dur)[:5]
+    print("   longest waves (us, entries, start us):", [(round(float(dur[i]), 1), int(n[i]), round(float(late[i]), 1)) for i in order])
+    for lo, hi in ((1, 128), (128, 256), (256, 512), (512, 768), (768, 1024), (1024, 4096)):
+        sel = (n >= lo) & (n < hi)
+        if sel.sum():
+            print(f"   lists {lo:4d}..{hi:4d}: {int(sel.sum()):5d} waves, median {np.median(dur[sel]):6.1f} us = {np.median(dur[sel] / n[sel]) * 1e3:6.0f} ns per entry; "
+                  f"started at median {np.median(late[sel]):5.1f} us")
+
+
+def main():
+    import render_bench
+    model, cam, bg = render_bench.scene()
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=False, sync_free_raster=True)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        o = render(1, cam, model, pipe, bg)
+        sum(o[k].mean() for k in render_bench.PHASE1_KEYS).backward()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    slots = 4096 + 1024
+    words = 2 * 16 * slots
+    buf = torch.zeros(words, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib.gsr_debug_wave_trace(buf.data_ptr(), words), "trace")
+    step()
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib.gsr_debug_wave_trace(None, 0), "trace")
+    rec = buf.cpu().numpy().view(np.uint64).reshape(2, -1, 4)
+    report("blend forward (18 channels)", rec[0], lambda r: np.maximum(r[:, 2].astype(np.int64), 1))
+    report("blend backward (features)", rec[1], lambda r: np.maximum((r[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64), 1))
+
+
+if __name__ == "__main__":
+    main()
