@@ -35,6 +35,7 @@ DEFAULT_TILE_CULL = 1  # tuning knob "tile_cull": exact ellipse-vs-tile culling 
 DEFAULT_BWD_REDUCE = 3
 DEFAULT_TILE_ORDER = 1  # tuning knob "tile_order" (csrc/gsr_common.h: Options)
 DEFAULT_BLEND_LAYOUT = 0  # tuning knob "blend_layout"
+DEFAULT_BLEND_SEGMENTS = 8  # tuning knob "blend_segments": lists >= 8 / 4 x the frame's mean are walked in segments
 
 
 class GsrError(RuntimeError):

@@ -407,20 +407,23 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     s_red[wave][2] = kept;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t m = 0;
-    for (int w = 0; w < HB / WAVE; w++) m = max(m, s_red[w][1]);
-    s_thr = order_mode == 0 ? 0u : m;  // Options::tile_order: 0 natural order; the longest list (0: nothing to render)
-    order[0] = s_thr ? ((uint32_t)order_mode | (min(m, 0xFFFFFFu) << 8)) : 0u;
-    uint32_t b = 0, kp = 0;
-    for (int w = 0; w < HB / WAVE; w++) {
-      b += s_red[w][0];
-      kp += s_red[w][2];
+  if (wave == 0) {  // (the per-wave partials meet in the first wave's lanes: no serial loop of LDS reads on this workgroup's only path)
+    static_assert(HB / WAVE <= WAVE, "one lane per wave");
+    uint32_t b = lane < HB / WAVE ? s_red[lane][0] : 0u, m = lane < HB / WAVE ? s_red[lane][1] : 0u, kp = lane < HB / WAVE ? s_red[lane][2] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      b += __shfl_xor(b, d, WAVE);
+      kp += __shfl_xor(kp, d, WAVE);
+      m = max(m, (uint32_t)__shfl_xor((int)m, d, WAVE));
     }
-    s_busy = b;
-    s_kept = kp;
-    s_extra = 0u;
-    s_rec = 0u;
+    if (lane == 0) {
+      s_thr = order_mode == 0 ? 0u : m;  // Options::tile_order: 0 natural order; the longest list (0: nothing to render)
+      order[0] = s_thr ? ((uint32_t)order_mode | (min(m, 0xFFFFFFu) << 8)) : 0u;
+      s_busy = b;
+      s_kept = kp;
+      s_extra = 0u;
+      s_rec = 0u;
+    }
   }
   __syncthreads();
   const uint32_t mxn = s_thr;  // the longest list, 0: natural order (or nothing to render)
@@ -438,6 +441,7 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     // at least 1.5 x max(mean over the busy tiles, 256): a uniform cloud (C3: lists 150..355) cuts nothing.
     __syncthreads();
     const uint32_t target = max(s_busy ? s_kept / s_busy : 0u, 256u), extra_cap = seg_extra_max((uint32_t)tiles);
+    const float cls_scale = (float)(NCLS - 2) / (float)mxn;
     uint32_t mycls[PER_MAX], mycls0[PER_MAX], mysegs[PER_MAX];
 #pragma unroll
     for (int k = 0; k < PER_MAX; k++) {
@@ -447,29 +451,28 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
       if (k < per && t < tiles) {
         const uint32_t n = cnt[k];
         uint32_t nseg = 1u;
-        if (segments && n >= target + target / 2u) {
-          nseg = min((uint32_t)SEG_MAX, (n + target / 2u) / target);
+        if (segments && 4u * n >= (uint32_t)segments * target) {  // (segments = the outlier threshold in quarters of the mean)
+          nseg = max(2u, min((uint32_t)SEG_MAX, (n + target / 2u) / target));
           if (atomicAdd(&s_extra, nseg - 1u) + (nseg - 1u) > extra_cap) nseg = 1u;  // the frame's extra slots are used up: walked whole
         }
         if (nseg > 1u) ckpt_base[t] = atomicAdd(&s_rec, nseg);  // (<= 2 records per extra slot: inside ckpt_records())
         // a cut tile's FIRST slot stays in the class of the whole list -- the forward walks the list whole from that slot and must
         // start as early as before; the other pieces are sorted by the piece's length
-        const uint32_t cost = nseg > 1u ? (uint32_t)segment_len((int)n, (int)nseg) : n;
-        mycls0[k] = n == 0u ? 0u : 1u + (uint32_t)(((uint64_t)n * (NCLS - 2)) / mxn);  // 1 .. NCLS - 1
-        mycls[k] = n == 0u ? 0u : 1u + (uint32_t)(((uint64_t)min(cost, mxn) * (NCLS - 2)) / mxn);
+        // (classes by a float multiply: the order of near-equal lengths is of no consequence, a 64-bit division per tile is)
+        mycls0[k] = n == 0u ? 0u : 1u + min((uint32_t)(NCLS - 2), (uint32_t)((float)n * cls_scale));  // 1 .. NCLS - 1
+        mycls[k] = mycls0[k];
+        if (nseg > 1u) mycls[k] = 1u + min((uint32_t)(NCLS - 2), (uint32_t)((float)segment_len((int)n, (int)nseg) * cls_scale));
         mysegs[k] = nseg;
         atomicAdd(&s_ccount[mycls0[k]], 1u);
         if (nseg > 1u) atomicAdd(&s_ccount[mycls[k]], nseg - 1u);
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t run = 0;
-      for (int c = NCLS - 1; c >= 0; c--) {
-        s_cbase[c] = run;
-        run += s_ccount[c];
-      }
-      order[1] = run;  // visiting slots of this frame: tiles + extra segments
+    if (wave == 0) {  // class bases, longest class first: one wave scan instead of 64 dependent LDS round trips
+      static_assert(NCLS == WAVE, "one lane per class");
+      const uint32_t v = s_ccount[NCLS - 1 - lane], incl = wave_incl_scan(v);
+      s_cbase[NCLS - 1 - lane] = incl - v;
+      if (lane == WAVE - 1) order[1] = incl;  // visiting slots of this frame: tiles + extra segments
     }
     __syncthreads();
 #pragma unroll
@@ -531,12 +534,9 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int c = NCLS - 1; c >= 0; c--) {
-      s_cbase[c] = run;
-      run += s_ccount[c];
-    }
+  if (wave == 0) {
+    const uint32_t v = s_ccount[NCLS - 1 - lane];
+    s_cbase[NCLS - 1 - lane] = wave_incl_scan(v) - v;
   }
   __syncthreads();
 #pragma unroll
@@ -924,7 +924,7 @@ bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity) 
 }
 
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *ckpt_base, bool segments, uint32_t *dev_status,
+                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *ckpt_base, int segments, uint32_t *dev_status,
                    bool check_prefilter, bool scan_fused, const Options &opt, hipStream_t stream, int debug) {
   const size_t tiles = (size_t)grid_x * grid_y;
   if (grid_x >= 1024 || grid_y >= 1024) {
@@ -975,7 +975,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     }
     hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb + 1), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
                        b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order, grid_x,
-                       ckpt_base, segments ? 1 : 0);
+                       ckpt_base, segments);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;

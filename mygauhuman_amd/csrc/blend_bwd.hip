@@ -847,10 +847,16 @@ constexpr int FX_TRI2 = 4 * 3 * 16;      // floats of one colour triple's second
 #define FX_FULL_ROWS false
 #endif
 
-__global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const BlendBwdArgs a) {
-  constexpr int CE = CE_MAX, NT = CE / 3;
-  __shared__ __attribute__((aligned(16))) float s_rw[WAVE * FX_LROW];  // 768 floats: hop 1; hop 2: base [0, 320) + one triple [320, 512)
-  constexpr int XS4 = (CE + 3) / 4;  // float4s per survivor row of channel colours (18 channels: 80 bytes, whole 16-byte reads)
+// NL = how many of the six channel triples carry a gradient (popcount of the image mask).  Everything per-channel is sized by it:
+// the survivor rows in LDS hold the LIVE triples only (gathered as such: 12 bytes per live triple instead of the 72-byte row), and so
+// do the per-pixel gradient registers, the dot product per contributing pair and the second-hop passes.  Phase 1 of the training
+// loss (train.py:256-286: image, alpha, normal, axis) has two live triples: 6 channels instead of 18 everywhere -- 24 registers and
+// 12 FMAs per pair less than the all-channel kernel, one more wave per SIMD.
+template <int NL>
+__device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs &a) {
+  constexpr int CE = CE_MAX, CL = 3 * NL;
+  __shared__ __attribute__((aligned(16))) float s_rw[WAVE * FX_LROW];  // 768 floats: hop 1; hop 2: base [0, 320) + two triples [320, 704)
+  constexpr int XS4 = CL > 0 ? (CL + 3) / 4 : 1;  // float4s per survivor row of live channel colours (whole 16-byte reads)
   __shared__ float4 s_x[FB * XS4];
   __shared__ float4 s0[FB], s1[FB], s2[FB];
   __shared__ uint32_t s_id[FB + 4];
@@ -890,22 +896,27 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
   const float dpix2 = inside ? a.dL_dpix[2 * plane + p] : 0.f;
   const float ddep = inside ? a.dL_ddepth[p] : 0.f, dalp = inside ? a.dL_dalpha[p] : 0.f;
   float bgd = bg0 * dpix0 + bg1 * dpix1 + bg2 * dpix2;
-  float dxp[CE];
+  uint32_t live_t[NL > 0 ? NL : 1];  // the live triples, ascending (wave-uniform)
+  {
+    uint32_t m = mask;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      live_t[j] = (uint32_t)__builtin_ctz(m | 0x40u);
+      m &= m - 1u;
+    }
+  }
+  float dxp[CL > 0 ? CL : 1];
   {
     // table rows 0..2: the colour image's gradient (always live); then the live extra channels
     s_dx[0 * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dpix0;
     s_dx[1 * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dpix1;
     s_dx[2 * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dpix2;
-    int ci = 3;  // index among the table rows (wave-uniform)
 #pragma unroll
-    for (int c = 0; c < CE; c++) {
-      const bool on = (mask >> (c / 3)) & 1u;
-      dxp[c] = (on && inside) ? a.dL_dextra_tri[c / 3][(size_t)(c % 3) * plane + p] : 0.f;
+    for (int c = 0; c < CL; c++) {
+      const float *img = a.dL_dextra_tri[live_t[c / 3] % (CE / 3)];
+      dxp[c] = inside ? img[(size_t)(c % 3) * plane + p] : 0.f;
       bgd += (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2)) * dxp[c];
-      if (on) {
-        s_dx[ci * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dxp[c];
-        ci++;
-      }
+      s_dx[(3 + c) * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dxp[c];
     }
   }
   const float Tb = T * bgd;  // T_final * (bg . dL_dpix), over every colour channel
@@ -918,8 +929,10 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
     float xb = dpix0 * (rf[256] - rb[256]) + dpix1 * (rf[512] - rb[512]) + dpix2 * (rf[768] - rb[768]) + ddep * (rf[1024] - rb[1024]) +
                dalp * (rf[1280] - rb[1280]);
 #pragma unroll
-    for (int c = 0; c < CE; c++)
-      if ((mask >> (c / 3)) & 1u) xb += dxp[c] * (rf[(6 + c) * 256] - rb[(6 + c) * 256]);
+    for (int c = 0; c < CL; c++) {
+      const uint32_t pl = (6u + 3u * live_t[c / 3] + (uint32_t)(c % 3)) * 256u;
+      xb += dxp[c] * (rf[pl] - rb[pl]);
+    }
     X = inside ? xb : 0.f;
   }
   int maxlast = lastc;
@@ -946,8 +959,10 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
   };
   auto fetch_rest = [&](Row &r) {
     r.g2 = s2[r.k];
+    if (CL > 0) {
 #pragma unroll
-    for (int c = 0; c < XS4; c++) r.x[c] = s_x[r.k * XS4 + c];
+      for (int c = 0; c < XS4; c++) r.x[c] = s_x[r.k * XS4 + c];
+    }
   };
   auto fetch = [&](Row &r, int k) {  // (a row beyond the last survivor is stale LDS: read, never used)
     r.k = min(k, FB - 1);
@@ -983,9 +998,17 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
         s1[sl] = make_float4((-0.5f * L2E) * r1.x, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(n - 1 - idx)), r1.y);
         s2[sl] = make_float4(r1.w, r2.x, r2.y, r1.z);
         s_id[sl] = id;
-        const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
+        if (CL > 0) {  // the LIVE triples of the Gaussian's channel row only
+          const float *xs = a.extra + (size_t)id * CE;
+          float *dst = reinterpret_cast<float *>(&s_x[sl * XS4]);
 #pragma unroll
-        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[sl * XS4])[q] = xs[q];
+          for (int j = 0; j < NL; j++) {
+            const float *t3 = xs + 3u * live_t[j];
+            dst[3 * j + 0] = t3[0];
+            dst[3 * j + 1] = t3[1];
+            dst[3 * j + 2] = t3[2];
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1021,9 +1044,8 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
             const float Tn = T * rc;  // transmittance in front of this Gaussian
             const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
             float e = r.g2.x * dpix0 + r.g2.y * dpix1 + r.g2.z * dpix2 + r.g2.w * ddep + dalp;
-            // (every channel: dxp is zero where the image has no gradient -- twelve spare FMAs at most, no branch, no wait)
 #pragma unroll
-            for (int c = 0; c < CE; c++) {
+            for (int c = 0; c < CL; c++) {
               const float4 v = r.x[c / 4];
               e += (c % 4 == 0 ? v.x : (c % 4 == 1 ? v.y : (c % 4 == 2 ? v.z : v.w))) * dxp[c];
             }
@@ -1094,9 +1116,6 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
           t2[24] = ka;
           t2[32] = kb;
           // ---- channel sums: the live triples take the second hop TWO at a time (the first pair rides with the base sums)
-          int ci = 3, pend = 0;
-          uint32_t pend_t0 = 0, pend_t1 = 0;
-          bool base_done = false;
           auto base_atomic = [&]() {
             constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;  // bit k: upper half (see blend_backward_kernel)
             constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;   // nibble k: which of qa..kb (0..4)
@@ -1108,44 +1127,41 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
             if (row_live && kcol < NACC) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + kcol], vsum);
           };
 #pragma unroll
-          for (int t = 0; t < NT; t++) {
-            if (!((mask >> t) & 1u)) continue;  // wave-uniform
-            float x3[3];
+          for (int j0 = 0; j0 < NL; j0 += 2) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int npair = j0 + 1 < NL ? 2 : 1;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-              const float4 d4 = *reinterpret_cast<const float4 *>(&s_dx[(ci + j) * WAVE + (int)(lane & 15u) * 4]);
-              x3[j] = (rw[0].y * d4.x + rw[1].y * d4.y) + (rw[2].y * d4.z + rw[3].y * d4.w);
-            }
-            ci += 3;
-            float *t3 = &s_rw[FX_BASE2 + pend * FX_TRI2 + (row * 3) * 16 + (int)(lane & 15u)];
-            t3[0] = x3[0];
-            t3[16] = x3[1];
-            t3[32] = x3[2];
-            if (pend == 0) pend_t0 = (uint32_t)t;
-            else pend_t1 = (uint32_t)t;
-            pend++;
-            if (pend == 2 || (mask >> (t + 1)) == 0u) {  // (wave-uniform) a pair is complete, or this was the last live triple
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              if (!base_done) {
-                base_done = true;
-                base_atomic();
+            for (int jj2 = 0; jj2 < 2; jj2++) {
+              if (jj2 < npair) {
+                float x3[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                  const float4 d4 = *reinterpret_cast<const float4 *>(&s_dx[(3 + 3 * (j0 + jj2) + k) * WAVE + (int)(lane & 15u) * 4]);
+                  x3[k] = (rw[0].y * d4.x + rw[1].y * d4.y) + (rw[2].y * d4.z + rw[3].y * d4.w);
+                }
+                float *t3 = &s_rw[FX_BASE2 + jj2 * FX_TRI2 + (row * 3) * 16 + (int)(lane & 15u)];
+                t3[0] = x3[0];
+                t3[16] = x3[1];
+                t3[32] = x3[2];
               }
-              {  // lane (row, k < 6): column k % 3 of pending triple k / 3
-                const int which = kcol >= 3 ? 1 : 0, k3 = kcol < 6 ? kcol - 3 * which : 0;
-                const float4 *src16 = reinterpret_cast<const float4 *>(&s_rw[FX_BASE2 + which * FX_TRI2 + (row * 3 + k3) * 16]);
-                const float4 v0 = src16[0], v1 = src16[1], v2 = src16[2], v3 = src16[3];
-                const float xs = (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) +
-                                 (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
-                const uint32_t tt = which ? pend_t1 : pend_t0;
-                if (row_live && kcol < 3 * pend) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + NACC + 3 * tt + k3], xs);
-              }
-              __builtin_amdgcn_wave_barrier();  // the next pair's (or the next group's) stores stay behind these reads
-              pend = 0;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (j0 == 0) base_atomic();
+            {  // lane (row, k < 6): column k % 3 of the pair's triple k / 3
+              const int which = kcol >= 3 ? 1 : 0, k3 = kcol < 6 ? kcol - 3 * which : 0;
+              const float4 *src16 = reinterpret_cast<const float4 *>(&s_rw[FX_BASE2 + which * FX_TRI2 + (row * 3 + k3) * 16]);
+              const float4 v0 = src16[0], v1 = src16[1], v2 = src16[2], v3 = src16[3];
+              const float xs = (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w))) +
+                               (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
+              const uint32_t tt = (which && npair == 2) ? live_t[(j0 + 1) % (NL > 0 ? NL : 1)] : live_t[j0 % (NL > 0 ? NL : 1)];
+              if (row_live && kcol < 3 * npair) atomicAdd(&a.grad_rows[(size_t)gid * GROWX + NACC + 3 * tt + k3], xs);
+            }
+            __builtin_amdgcn_wave_barrier();  // the next pair's (or the next group's) stores stay behind these reads
           }
-          if (!base_done) {  // no live triple at all: the base sums' second hop alone
+          if (NL == 0) {  // no live triple at all: the base sums' second hop alone
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1167,6 +1183,22 @@ __global__ __launch_bounds__(WAVE) void blend_backward_features_kernel(const Ble
 }
 
 
+// one kernel per number of live triples, each told how many waves per SIMD its registers should leave room for (the register
+// allocator then fits 96 / 128 VGPRs instead of stopping two registers above the step)
+#define GSR_FEATURES_KERNEL(NL, WAVES)                                                                                        \
+  __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void blend_backward_features_kernel_##NL( \
+      const BlendBwdArgs a) {                                                                                                 \
+    blend_backward_features_body<NL>(a);                                                                                      \
+  }
+GSR_FEATURES_KERNEL(0, 5)
+GSR_FEATURES_KERNEL(1, 5)
+GSR_FEATURES_KERNEL(2, 5)
+GSR_FEATURES_KERNEL(3, 4)
+GSR_FEATURES_KERNEL(4, 4)
+GSR_FEATURES_KERNEL(5, 4)
+GSR_FEATURES_KERNEL(6, 4)
+#undef GSR_FEATURES_KERNEL
+
 int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
@@ -1186,7 +1218,17 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     }
     if (opt.blend_bwd_reduce == 3) {  // reductions through LDS; dynamic LDS = the image-gradient table of the live channels
       const unsigned live = 3u * (unsigned)__builtin_popcount(a.extra_mask & 0x3Fu);
-      hipLaunchKernelGGL(blend_backward_features_kernel, dim3(slots * 4), dim3(WAVE), (live + 3u) * WAVE * sizeof(float), stream, a);
+      const dim3 grid(slots * 4), block(WAVE);
+      const size_t lds = (live + 3u) * WAVE * sizeof(float);
+      switch (live / 3u) {  // (the kernel is built per number of live triples: rows, registers and passes sized by it)
+        case 0: hipLaunchKernelGGL(blend_backward_features_kernel_0, grid, block, lds, stream, a); break;
+        case 1: hipLaunchKernelGGL(blend_backward_features_kernel_1, grid, block, lds, stream, a); break;
+        case 2: hipLaunchKernelGGL(blend_backward_features_kernel_2, grid, block, lds, stream, a); break;
+        case 3: hipLaunchKernelGGL(blend_backward_features_kernel_3, grid, block, lds, stream, a); break;
+        case 4: hipLaunchKernelGGL(blend_backward_features_kernel_4, grid, block, lds, stream, a); break;
+        case 5: hipLaunchKernelGGL(blend_backward_features_kernel_5, grid, block, lds, stream, a); break;
+        default: hipLaunchKernelGGL(blend_backward_features_kernel_6, grid, block, lds, stream, a); break;
+      }
       return GSR_OK;
     }
     hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(slots * 4), dim3(WAVE), 0, stream, a);

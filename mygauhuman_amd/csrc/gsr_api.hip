@@ -125,7 +125,7 @@ static int set_option(Options &o, const char *key, int v) {
     if (v != 0 && v != 1) return bad("0 (quadrant waves) or 1 (4x4 blocks, four survivors per step)");
     o.blend_layout = v;
   } else if (!strcmp(key, "blend_segments")) {
-    if (v != 0 && v != 1) return bad("0 or 1");
+    if (v < 0 || v > 64) return bad("0 (never) or the outlier threshold in quarters of the frame's mean list length (4 .. 64)");
     o.blend_segments = v;
   } else if (!strcmp(key, "blend_prio")) {
     if (v < 0 || v > 4) return bad("0, 1 (issue priority by list length) or 2..4 (MEASUREMENT ONLY: render the longest lists alone)");
@@ -420,8 +420,8 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   prof_begin(PROF_BINNING, stream);
   if (R_host < 0 || opt.binning_mode == GSR_BINNING_TILE_BUCKET) {
     // list segments need the forward variant that writes the checkpoints (blend_forward_kernel<1, .>)
-    const bool segments = opt.blend_segments && opt.tile_order == 1 && opt.blend_layout == 0 && !opt.blend_fwd_dma &&
-                          (in.n_extra != 0 || opt.blend_fwd_waves == 4);
+    const int segments = (opt.tile_order == 1 && opt.blend_layout == 0 && !opt.blend_fwd_dma && (in.n_extra != 0 || opt.blend_fwd_waves == 4))
+                             ? opt.blend_segments : 0;
     rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, img.order, img.ckpt_base, segments,
                         dev_status, in.prefiltered != 0, scan_fused, opt, stream, in.debug & 1);
     if (rc != GSR_OK) return rc;

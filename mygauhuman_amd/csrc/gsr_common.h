@@ -243,7 +243,8 @@ struct Options {
   int blend_bwd_reduce = 3;  // 3 LDS folds (default), 0 permlane / DPP folds, 1 MFMA on folded rows, 2 transposed MFMA contraction
   int deterministic = 0;     // backward: fixed-order reduction of the gradient rows instead of float atomics
   int blend_layout = 0;      // 0: a wave per 8x8 quadrant, one survivor at a time; 1: a wave per 4x4 block, four survivors per step (forward)
-  int blend_segments = 1;    // 1: the lists of outlier tiles are walked in segments by the backward (forward checkpoints), see ORDER_HDR
+  int blend_segments = 8;    // > 0: lists of at least blend_segments / 4 x the frame's mean list are walked in segments by the backward
+                             // (forward checkpoints), see ORDER_HDR; 0: never
   int blend_prio = 1;        // 1: blend waves take an issue priority from the length of their tile's list (list_priority)
   int debug_no_atomics = 0;  // MEASUREMENT ONLY: the plain blend backward without its gradient-row atomics (gradients are wrong)
 };
@@ -396,7 +397,7 @@ int launch_query_recs(int what, int P, const GeomState &g, void *dst, hipStream_
 // capacity = instances the binning buffer holds.  device_sized: the host does not know R; the kernels read it from
 // g.total, write dev_status[0] = R, dev_status[1] = (R > capacity) | 2 * (prefilter violation) and render nothing on overflow.
 int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int grid_y, size_t capacity, bool device_sized,
-                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *ckpt_base, bool segments, uint32_t *dev_status,
+                   BinningState &b, uint2 *ranges, uint32_t *order, uint32_t *ckpt_base, int segments, uint32_t *dev_status,
                    bool check_prefilter, bool scan_fused, const Options &opt, hipStream_t stream, int debug);
 // true if bucket_binning will take its atomics-free histogram path (which can also do the block-sums scan: scan_fused)
 bool bucket_uses_hist(const Options &opt, int P, size_t tiles, size_t capacity);

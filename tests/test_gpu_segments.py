@@ -37,9 +37,9 @@ def no_segments():
     from mygauhuman_amd import _lib
 
     def switch(on):
-        _lib.set_tuning("blend_segments", 1 if on else 0)
+        _lib.set_tuning("blend_segments", _lib.DEFAULT_BLEND_SEGMENTS if on else 0)
     yield switch
-    _lib.set_tuning("blend_segments", 1)
+    _lib.set_tuning("blend_segments", _lib.DEFAULT_BLEND_SEGMENTS)
 
 
 @pytest.mark.parametrize("mode", ["sh", "precomp"])

@@ -43,14 +43,22 @@ def report(name, rec, length_of):
 
 def main():
     import render_bench
-    model, cam, bg = render_bench.scene()
+    if os.environ.get("SCENE", "render_bench") == "bench":   # the frame of bench.py's render_200k lines
+        import bench
+        from mygauhuman_amd import human_synth
+        wl = bench.RENDER_WL
+        model, body = human_synth.build(wl["P"], wl["V"], torch.device("cuda", 0), seed=0)
+        cam = human_synth.view_camera(body, wl["W"], wl["H"], 0, n_views=8, device=torch.device("cuda", 0))
+        bg = torch.zeros(3, device="cuda")
+    else:
+        model, cam, bg = render_bench.scene()
     pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=False, sync_free_raster=True)
 
     def step():
         for p in model.parameters():
             p.grad = None
         o = render(1, cam, model, pipe, bg)
-        sum(o[k].mean() for k in render_bench.PHASE1_KEYS).backward()
+        sum(o[k].mean() for k in (render_bench.ALL_KEYS if os.environ.get("KEYS") == "all" else render_bench.PHASE1_KEYS)).backward()
     for _ in range(10):
         step()
     torch.cuda.synchronize()
