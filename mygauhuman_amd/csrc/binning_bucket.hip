@@ -19,12 +19,13 @@
 // The result (point_list, ranges, sorted keys) is bit-identical to the global radix back-end; traffic drops from
 // ~150 B to ~30 B per instance and the kernel count from 20 to 4.
 #include <atomic>
+#include <type_traits>
 #include "expand.h"
 #include "gsr_common.h"
 
 namespace gsr {
 
-constexpr int SORT_BIG = 4096;  // LDS capacity (keys) of the workgroup sort used for lists > 512; longer lists: chunks + global merge
+constexpr int SORT_BIG = 2048;  // keys the workgroup sort of lists > 512 handles in LDS (two buffers of 16 KB); longer lists: chunks + global merge
 
 // One returning atomic per instance: the value it returns is the instance's arrival rank inside its tile, kept in
 // rank[instance] so that the scatter pass needs no second round of atomics.  Counter t lives at counts[t * CSTRIDE]:
@@ -656,7 +657,6 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t *b, int n, uint32_
 }
 
 constexpr int SORT_WAVE_MAX = 512;   // longest list one wave sorts by itself (8 runs of 64 + rank merge); longer ones: bucket_sort_kernel
-constexpr int SORT_RUN_MAX = 1024;   // longest run one wave sorts in registers inside bucket_sort_kernel (16 keys per lane)
 
 // ---- sort by runs + rank merge (lists of 65 .. 512 keys) ---------------------------------------------------------------
 // A full bitonic network over NREG x 64 keys costs log^2 stages over every register and needs a power-of-two size: a tile with
@@ -776,51 +776,83 @@ __device__ __forceinline__ void sort_big_tile(uint32_t tile, uint64_t *s_keys, c
   if (n <= LO || (!TAKES_OVERSIZE && n > CAP)) return;  // (the same for every thread of the workgroup)
   uint64_t *b = bucket + r.x;
   if (n <= SORT_LDS_MAX) {
-    int np = 1;
-    while (np < n) np <<= 1;
-    for (int i = threadIdx.x; i < np; i += blockDim.x) s_keys[i] = i < n ? b[i] : ~0ull;
+    // Runs of 64 sorted across the lanes in registers (as bucket_sort_wave_kernel), then log2(runs) levels of PAIRWISE MERGE BY RANK
+    // between two LDS buffers: every key finds how many keys of the sibling run are smaller by a binary search (keys are unique)
+    // and stores itself at (its index in its own run) + (that count).  A thread carries its eight keys through a level in lockstep:
+    // eight independent LDS reads per search step.  Padding (~0) sits only at the end of the LAST run, so it is never on the A side
+    // of a pair with a non-empty B side and every padded key still gets a position of its own.
+    // (Before: np = next power of two, four register sorts of np / 4 keys -- 45 stages over 8 keys per lane for a list of 1,100 --
+    // and the last levels of the bitonic network through LDS: 39.7 us per launch in the render() frame, ~700 lists of 513..1,398 keys.
+    // This form: 35 us, of which -- measured by leaving phases out -- 4.8 us the empty launch + work-list read, 1.6 us loads and
+    // stores, 8.5 us the run sorts, 21 us the five merge levels: 45 search steps of 8 random 8-byte LDS reads per thread.)
+    const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    constexpr int NW = 256 / WAVE;
+    const int runs = (n + WAVE - 1) / WAVE, N = runs * WAVE;
+    uint64_t *src = s_keys, *dst = s_keys + CAP;
+    auto sort_runs = [&](auto nr_tag) {
+      constexpr int NR = decltype(nr_tag)::value;
+      uint64_t key[NR];
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        const int i = ((int)wave + q * NW) * WAVE + (int)lane;
+        key[q] = i < n ? b[i] : ~0ull;
+      }
+      run_levels<NR, 2>(key, lane);
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        const int i = ((int)wave + q * NW) * WAVE + (int)lane;
+        if (i < N) src[i] = key[q];
+      }
+    };
+    const int per_wave = (runs + NW - 1) / NW;
+    static_assert(CAP / WAVE / NW <= 8, "at most eight runs per wave");
+    if (per_wave <= 2) sort_runs(std::integral_constant<int, 2>{});
+    else if (per_wave <= 4) sort_runs(std::integral_constant<int, 4>{});
+    else sort_runs(std::integral_constant<int, 8>{});
     __syncthreads();
-    if (np >= 4 * WAVE * 4) {
-      // every wave sorts its quarter of the list in REGISTERS (runs of np / 4 keys, at most SORT_RUN_MAX: 4, 8 or 16 keys per
-      // lane, no barriers; odd runs descending = ascending sort of the complemented keys), then only the last merge levels of
-      // the network run through LDS: 19..25 barrier stages instead of 55..91.  (Before: runs of 1024 only, i.e. a list of 1100
-      // keys kept two of the four waves busy with 16-register sorts and lists of 513..1024 were sorted by ONE wave.)
-      const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
-      const int nw = (int)(blockDim.x / WAVE);
-      const int rl = min(SORT_RUN_MAX, np / nw);
-      for (int c = (int)wave; c < np / rl; c += nw) {
-        const uint64_t flip = (c & 1) ? ~0ull : 0ull;
-        uint64_t *run = s_keys + (size_t)c * rl;
-        if (rl == 16 * WAVE) {
-          uint64_t key[16];
+    constexpr int KPT = CAP / 256;  // keys per thread
+    for (int L = WAVE; L < N; L <<= 1) {
+      uint64_t key[KPT];
+      int other0[KPT], len[KPT], pos[KPT];
+      uint32_t c[KPT];
 #pragma unroll
-          for (int q = 0; q < 16; q++) key[q] = run[q * WAVE + (int)lane] ^ flip;
-          wave_bitonic_sort<16>(key, lane);
+      for (int q = 0; q < KPT; q++) {
+        const int i = (int)threadIdx.x + q * 256;
+        const int a0 = (i / (2 * L)) * (2 * L), a1 = min(N, a0 + L), b1 = min(N, a1 + L);
+        const bool in_a = i < a1;
+        key[q] = i < N ? src[i] : ~0ull;
+        other0[q] = in_a ? a1 : a0;
+        len[q] = i < N ? (in_a ? b1 - a1 : a1 - a0) : 0;
+        pos[q] = a0 + (in_a ? i - a0 : i - a1);
+        c[q] = 0u;
+      }
+      // (every read is unconditional -- the index is clamped into the list, the comparison masked -- so that a step is eight LDS
+      // reads in flight and one wait, not eight round trips behind eight branches)
+      for (int step = L / 2; step >= 1; step >>= 1) {
+        uint64_t v[KPT];
 #pragma unroll
-          for (int q = 0; q < 16; q++) run[q * WAVE + (int)lane] = key[q] ^ flip;
-        } else if (rl == 8 * WAVE) {
-          uint64_t key[8];
+        for (int q = 0; q < KPT; q++) v[q] = src[min(other0[q] + (int)c[q] + step - 1, N - 1)];
 #pragma unroll
-          for (int q = 0; q < 8; q++) key[q] = run[q * WAVE + (int)lane] ^ flip;
-          wave_bitonic_sort<8>(key, lane);
+        for (int q = 0; q < KPT; q++) c[q] += ((int)c[q] + step - 1 < len[q] && v[q] < key[q]) ? (uint32_t)step : 0u;
+      }
+      {  // (the last element of the sibling run: the steps above cover indices 0 .. L - 2)
+        uint64_t v[KPT];
 #pragma unroll
-          for (int q = 0; q < 8; q++) run[q * WAVE + (int)lane] = key[q] ^ flip;
-        } else {
-          uint64_t key[4];
+        for (int q = 0; q < KPT; q++) v[q] = src[min(other0[q] + (int)c[q], N - 1)];
 #pragma unroll
-          for (int q = 0; q < 4; q++) key[q] = run[q * WAVE + (int)lane] ^ flip;
-          wave_bitonic_sort<4>(key, lane);
-#pragma unroll
-          for (int q = 0; q < 4; q++) run[q * WAVE + (int)lane] = key[q] ^ flip;
+        for (int q = 0; q < KPT; q++) {
+          c[q] += ((int)c[q] < len[q] && v[q] < key[q]) ? 1u : 0u;
+          const int i = (int)threadIdx.x + q * 256;
+          if (i < N) dst[pos[q] + (int)c[q]] = key[q];
         }
       }
       __syncthreads();
-      bitonic_sort_block(s_keys, np, 2 * rl);
-    } else if (np > 1) {
-      bitonic_sort_block(s_keys, np);
+      uint64_t *t = src;
+      src = dst;
+      dst = t;
     }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint64_t k = s_keys[i];
+      const uint64_t k = src[i];
       point_list[r.x + i] = (uint32_t)k;
       keys_sorted[r.x + i] = ((uint64_t)tile << 32) | (k >> 32);
     }
@@ -881,7 +913,7 @@ __device__ __forceinline__ void sort_big_tile(uint32_t tile, uint64_t *s_keys, c
 template <int CAP, int LO, bool TAKES_OVERSIZE>
 __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, uint64_t *bucket, uint32_t *point_list,
                                                          uint64_t *keys_sorted, const uint32_t *big_list, const uint32_t *big_count) {
-  __shared__ uint64_t s_keys[CAP];
+  __shared__ uint64_t s_keys[2 * CAP];  // two buffers: the merge levels go back and forth between them
   const uint32_t count = *big_count;
   for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
     sort_big_tile<CAP, LO, TAKES_OVERSIZE>(big_list[k], s_keys, ranges, bucket, point_list, keys_sorted);
