@@ -16,6 +16,13 @@
 // conservative, so it only removes work whose outcome is "skip".
 #include "gsr_common.h"
 
+#ifndef FWD_FULL_ROWS
+#define FWD_FULL_ROWS false
+#endif
+#ifndef FWD_FEATURE_WPG
+#define FWD_FEATURE_WPG 2
+#endif
+
 namespace gsr {
 
 // bijective XCD-aware remap: consecutive work items (which share Gaussians) land on the same XCD / L2
@@ -27,37 +34,55 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
 
 // CE > 0: fused multi-feature blend -- CE extra colour channels (a.extra[P][CE]) are composited with the same weights in
 // the same pass (the reference rasterises seven times per frame for them, gaussian_renderer/__init__.py:203-272).
+// waves per workgroup: the quadrant waves of a tile that are launched together (SLOTS == 1)
 template <int SLOTS, int CE>
-__global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_kernel(const BlendFwdArgs a) {
+constexpr int fwd_wpg() { return SLOTS == 1 ? (CE > 0 ? FWD_FEATURE_WPG : 4) : 1; }
+
+template <int SLOTS, int CE>
+__global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_kernel(const BlendFwdArgs a) {
   // SLOTS == 1: the four quadrant waves of a tile form ONE workgroup -- still independent of each other, there is no workgroup
   // barrier anywhere -- so that they run on one CU and fetch the tile's records through one L1: 104 -> 97 us at C3, 153 -> 146 us
-  // in the render() frame (the same layout changed nothing for the backward kernels, which keep one wave per workgroup)
-  constexpr int WPG = SLOTS == 1 ? 4 : 1;
+  // in the render() frame (the same layout changed nothing for the backward kernels, which keep one wave per workgroup).
+  // With 18 extra channels a workgroup is HALF a tile (two waves, 15 KB of LDS): four-wave workgroups of 30.7 KB were only placed
+  // four to a CU although five fit on paper.
+  constexpr int WPG = fwd_wpg<SLOTS, CE>();
+  constexpr uint32_t H = SLOTS == 1 ? 4 / WPG : 1;  // workgroups per tile
   const uint32_t wv = threadIdx.x / WAVE;
   constexpr int WPT = 4 / SLOTS;  // waves per tile
-  constexpr int XS = (CE + 3) / 4 * 4;  // floats per survivor row of extra channels: whole 16-byte reads (18 channels: 20 floats)
-  __shared__ float4 s_x_all[CE > 0 ? WPG * WAVE * XS / 4 : 1];  // survivors' extra channels
+  // survivors' extra channels: rows of XS2 float2 (72 bytes for 18 channels: with the records' 48 that is 30.7 KB per workgroup, five
+  // workgroups per CU -- padded to 80 bytes for whole 16-byte reads it is 32.8 KB and four)
+  constexpr int XS2 = CE > 0 ? CE / 2 : 1;
+  __shared__ float2 s_x_all[CE > 0 ? WPG * WAVE * XS2 : 1];
   __shared__ float4 s0_all[WPG * WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   // what the cut-off test needs sits in s0 + the first half of s1, what only a blending survivor needs in the second half of s1 +
   // s2: each branch's LDS reads are whole 8- / 16-byte accesses (a 4-byte broadcast read costs as many LDS cycles as an 8-byte one,
   // and the kernel runs the LDS at ~2/3 of its cycles)
   __shared__ float4 s1_all[WPG * WAVE];     // qc, log2(255*opacity) | list position + 1 (bits), opacity   (qc = -conic_c log2(e)/2)
   __shared__ float4 s2_all[WPG * WAVE];     // r, g, b, depth
-  float4 *s_x = s_x_all + (CE > 0 ? wv * WAVE * XS / 4 : 0);
+  float2 *s_x = s_x_all + (CE > 0 ? wv * WAVE * XS2 : 0);
   float4 *s0 = s0_all + wv * WAVE, *s1 = s1_all + wv * WAVE, *s2 = s2_all + wv * WAVE;
 
   const unsigned long long trace_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   uint32_t tile, part, nseg = 1;
-  if constexpr (WPG == 4) {
-    // (the launch covers tile_slots_max() workgroups; the frame's own mode word says how many visiting slots it has)
+  if constexpr (SLOTS == 1) {
+    // (the launch covers tile_slots_max() * H workgroups; the frame's own mode word says how many visiting slots it has)
     const int omode = tile_order_mode(a.order);
     const uint32_t n_slots = tile_slots_of(a.order, a.grid_x, a.grid_y, omode);
-    const uint32_t slot = omode ? blockIdx.x : (blockIdx.x < n_slots ? xcd_remap(blockIdx.x, n_slots) : n_slots);
+    // workgroup -> (visiting slot, part of the tile): consecutive slots on different XCDs (workgroup % 8), the H parts of a slot on one
+    uint32_t slot, sub;
+    if (H == 1) {
+      slot = blockIdx.x, sub = 0u;
+    } else {
+      const uint32_t full = (n_slots / 8u) * 8u * H;
+      slot = blockIdx.x < full ? (blockIdx.x / (8u * H)) * 8u + blockIdx.x % 8u : blockIdx.x / H;
+      sub = blockIdx.x < full ? (blockIdx.x / 8u) % H : blockIdx.x % H;
+    }
+    if (!omode) slot = slot < n_slots ? xcd_remap(slot, n_slots) : n_slots;
     const uint32_t entry = tile_of_slot(a.order, omode, slot, n_slots);
     // (workgroup-uniform) the forward walks a list whole -- the early exit decides where it ends -- from the slot of its first segment
     if (entry == ORDER_NO_TILE || order_entry_seg(entry) != 0u) return;
     tile = order_entry_tile(entry), nseg = order_entry_nseg(entry);
-    part = wv;
+    part = sub * WPG + wv;
   } else {
     const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
     tile = item / WPT, part = item % WPT;
@@ -164,7 +189,7 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
       if (CE > 0) {
         const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
 #pragma unroll
-        for (int q = 0; q < CE / 2; q++) reinterpret_cast<float2 *>(&s_x[slot * (XS / 4)])[q] = xs[q];
+        for (int q = 0; q < CE / 2; q++) s_x[slot * XS2 + q] = xs[q];
       }
     }
     // the next batch's records and the list entries of the batch after it go out AFTER this batch's channel-colour loads
@@ -188,22 +213,29 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
     // nothing overlaps, and in a frame of unequal lists the kernel lasts as long as the wave with the longest list however many
     // other waves fill the gaps (tools/tile_cost_census.py): the chain, not the issue rate, is the time.
     // (two register sets, A and B, used in turn -- an explicit 2x unroll: a rotating single set costs ~30 v_mov per survivor)
+    // FWD_FULL_ROWS: whole rows travel ahead (no exposed LDS round trip; 32 registers per set with 18 channels).  Otherwise only the
+    // cut-off rows do, and a contributing survivor fetches its colour + channel rows in one round trip (16 registers less per set).
+    constexpr bool FULL = FWD_FULL_ROWS || CE == 0;
     struct Row {
       float4 g0, g1, g2;
-      float4 x[CE > 0 ? XS / 4 : 1];
+      float2 x[XS2];
+      int kk;
     };
-    auto fetch = [&](Row &r, int k) {  // (a row beyond the last survivor is stale LDS: read, never used)
-      const int kk = min(k, WAVE - 1);
-      r.g0 = s0[kk];
-      r.g1 = s1[kk];
-      r.g2 = s2[kk];
+    auto fetch_rest = [&](Row &r) {
+      r.g2 = s2[r.kk];
       if (CE > 0) {
-        const float4 *xr = &s_x[kk * (XS / 4)];
+        const float2 *xr = &s_x[r.kk * XS2];
 #pragma unroll
-        for (int c = 0; c < XS / 4; c++) r.x[c] = xr[c];
+        for (int c = 0; c < XS2; c++) r.x[c] = xr[c];
       }
     };
-    auto blend_one = [&](const Row &r) {
+    auto fetch = [&](Row &r, int k) {  // (a row beyond the last survivor is stale LDS: read, never used)
+      r.kk = min(k, WAVE - 1);
+      r.g0 = s0[r.kk];
+      r.g1 = s1[r.kk];
+      if constexpr (FULL) fetch_rest(r);
+    };
+    auto blend_one = [&](Row &r) {
 #pragma unroll
       for (int s = 0; s < SLOTS; s++) {
         const float dx = r.g0.x - pxf[s], dy = r.g0.y - pyf[s];
@@ -211,6 +243,7 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
         // cheap necessary condition for alpha >= 1/255:  log2(255*o) + power*log2(e) >= 0  (0.02 safety margin)
         const bool pre = !(p2 > 0.0f) && ((p2 + r.g1.y) >= dbias[s]);
         if (__ballot(pre) != 0ull) {
+          if constexpr (!FULL) fetch_rest(r);
           const float alpha = fminf(0.99f, r.g1.w * __builtin_amdgcn_exp2f(p2));
           const bool hit = pre && !(alpha < 1.0f / 255.0f);
           const float test_T = T[s] * (1.0f - alpha);
@@ -225,10 +258,7 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
           Wt[s] += w;
           if (CE > 0) {
 #pragma unroll
-            for (int c = 0; c < CE; c++) {
-              const float4 v = r.x[c / 4];
-              X[s][c] += (c % 4 == 0 ? v.x : (c % 4 == 1 ? v.y : (c % 4 == 2 ? v.z : v.w))) * w;
-            }
+            for (int c = 0; c < CE; c++) X[s][c] += (c % 2 == 0 ? r.x[c / 2].x : r.x[c / 2].y) * w;
           }
           T[s] = blend ? test_T : T[s];
           last[s] = blend ? __float_as_uint(r.g1.z) : last[s];
@@ -250,7 +280,7 @@ __global__ __launch_bounds__(WAVE * (SLOTS == 1 ? 4 : 1)) void blend_forward_ker
   if (nseg > 1u)
     while (next_rec < nseg) checkpoint(next_rec++);
   if (a.trace && lane == 0) {
-    unsigned long long *r = a.trace + ((size_t)blockIdx.x * 4u + wv) * 4u;
+    unsigned long long *r = a.trace + ((size_t)blockIdx.x * WPG + wv) * 4u;
     r[0] = trace_t0;
     r[1] = __builtin_amdgcn_s_memrealtime();
     r[2] = (unsigned long long)n;
@@ -718,7 +748,7 @@ int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t 
     else if (opt.blend_fwd_dma)
       hipLaunchKernelGGL(blend_forward_features_kernel, dim3(slots), dim3(WAVE * 4), 0, stream, a);
     else
-      hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(slots), dim3(WAVE * 4), 0, stream, a);
+      hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(slots * (4 / FWD_FEATURE_WPG)), dim3(WAVE * FWD_FEATURE_WPG), 0, stream, a);
     return GSR_OK;
   }
   if (opt.blend_layout == 1 && opt.blend_fwd_waves == 4) {
