@@ -163,7 +163,9 @@ GSR_HD inline uint32_t order_entry_nseg(uint32_t e) { return ((e >> 25) & 7u) + 
 GSR_HD inline int segment_len(int n, int nseg) { return ((n + nseg - 1) / nseg + 63) & ~63; }
 // the most EXTRA visiting slots (segments beyond a tile's first) a frame may use, and the checkpoint records that go with them
 // (a tile cut into s segments takes s records: s - 1 boundaries + the final state, <= 2 per extra slot)
-GSR_HD inline uint32_t seg_extra_max(uint32_t tiles) { return tiles / 4u; }
+// (tiles / 8: the close-up of a body uses 445 extra slots for its 4,096 tiles at the default threshold; when they run out the remaining
+// long lists are walked whole.  Every extra slot costs empty workgroups in uniform frames and 2 x 24 KB of checkpoint pool.)
+GSR_HD inline uint32_t seg_extra_max(uint32_t tiles) { return tiles / 8u; }
 GSR_HD inline size_t ckpt_records(size_t tiles) { return 2 * (size_t)seg_extra_max((uint32_t)tiles); }
 // mode word + the most visiting slots any mode needs: 4 x 2 blocks on a grid one tile wide pad every block from two tiles to eight
 // ((nsb + 7) * 8 <= (gx + 3)(gy + 1) + 56 <= 4 tiles + 63)
