@@ -121,14 +121,17 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   constexpr int NA = LFOLD ? 2 : (SEP ? (HIER ? 4 : 6) : NACC);
   constexpr int LROW = 12;  // floats per pixel lane in the transposition buffer: 4 x (r, w) + 4 pad (conflict-free b64 reads)
   __shared__ __attribute__((aligned(16))) float s_rw[LFOLD ? WAVE * LROW : 4];
-  __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 4];
+  // (LDS is handed out in 1,280-byte granules on this part -- 160 KB / 128: the plain kernel's 6,416 bytes took SIX of them, 21 waves per
+  // CU; at <= 6,400 it takes five and the registers' six waves per SIMD fit.  Hence no spare words below.)
+  __shared__ __attribute__((aligned(16))) float s_x[CE > 0 ? WAVE * CE : 1];
   __shared__ float4 s0[WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   // (layout as in blend_fwd.hip: the cut-off test reads s0 + s1, a contributing survivor additionally s2: whole 16-byte reads)
   __shared__ float4 s1[WAVE];     // qc, log2(255*opacity), front position (bits), opacity   (qc = -conic_c log2(e)/2)
   __shared__ float4 s2[WAVE];     // r, g, b, depth
-  __shared__ uint32_t s_id[WAVE + 4];
-  __shared__ uint32_t s_slot[DET ? WAVE + 4 : 1];
+  __shared__ uint32_t s_id[WAVE];
+  __shared__ uint32_t s_slot[DET ? WAVE : 1];
 
+  const unsigned long long trace_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   uint32_t tile, part, seg = 0, nseg = 1;
   if constexpr (WPT == 4) {
     const int omode = tile_order_mode(a.order);
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
         // after the swap folds row 0/1/2/3 = Gaussian g+0 / g+2 / g+1 / g+3; the LDS transposition reads row r = Gaussian g + r
         const int u_of_row = LFOLD ? row : (((row & 1) << 1) | (row >> 1));
         const bool row_live = ((anyhit >> u_of_row) & 1u) && (g + u_of_row < cnt);
-        const uint32_t gid = row_live ? s_id[g + u_of_row] : 0u;
+        const uint32_t gid = row_live ? s_id[min(g + u_of_row, WAVE - 1)] : 0u;
         if constexpr (SEP) {
           const float2 gxy = *reinterpret_cast<const float2 *>(&s0[g + u_of_row]);  // this row's Gaussian centre
           const float dxr = gxy.x - pxf[0];                // against this lane's column
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
           if constexpr (CE == 0) {
             v = jj == 7 ? kb : v;
             if constexpr (DET) {
-              if (row_live && colA < NACC) a.det_rows[(size_t)s_slot[g + u_of_row] * GROW + colA] = v;
+              if (row_live && colA < NACC) a.det_rows[(size_t)s_slot[min(g + u_of_row, WAVE - 1)] * GROW + colA] = v;
             } else {
               if (row_live && colA < NACC) atomicAdd(&a.grad_rows[(size_t)gid * ROWF + colA], v);
             }
@@ -583,6 +586,15 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
       }
     }
     __builtin_amdgcn_wave_barrier();  // keep the next batch's LDS writes behind this batch's reads
+  }
+  if constexpr (WPT == 4) {
+    if (a.trace && lane == 0) {
+      unsigned long long *r = a.trace + (size_t)blockIdx.x * 4u;
+      r[0] = trace_t0;
+      r[1] = __builtin_amdgcn_s_memrealtime();
+      r[2] = (unsigned long long)(walk_end - skip > 0 ? walk_end - skip : 0) | ((unsigned long long)n << 32);
+      r[3] = (unsigned long long)tile | ((unsigned long long)seg << 32);
+    }
   }
 }
 
@@ -840,7 +852,8 @@ int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t 
 // staged 32 at a time (half the plain kernel's batch) so that records + channel colours + transposition buffer + table stay
 // below 10 KB per wave for up to ~8 live channels: the occupancy curve in DESIGN.md punishes every wave lost.
 constexpr int FB = 32;                 // survivors staged at a time
-constexpr int FX_LROW = 12;            // floats per pixel lane in the transposition buffer (as LFOLD above)
+constexpr int FX_LROW = 10;            // floats per pixel lane in the transposition buffer: 4 x (r, w) + 2 pad (12 as in LFOLD above would
+                                       // cost 256 bytes that decide between six and seven LDS granules per wave, see s_rw)
 constexpr int FX_BASE2 = 4 * 2 * 5 * 8;  // floats of the base sums' second hop
 constexpr int FX_TRI2 = 4 * 3 * 16;      // floats of one colour triple's second hop (two triples per pass)
 #ifndef FX_FULL_ROWS
@@ -855,13 +868,16 @@ constexpr int FX_TRI2 = 4 * 3 * 16;      // floats of one colour triple's second
 template <int NL>
 __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs &a) {
   constexpr int CE = CE_MAX, CL = 3 * NL;
-  __shared__ __attribute__((aligned(16))) float s_rw[WAVE * FX_LROW];  // 768 floats: hop 1; hop 2: base [0, 320) + two triples [320, 704)
-  constexpr int XS4 = CL > 0 ? (CL + 3) / 4 : 1;  // float4s per survivor row of live channel colours (whole 16-byte reads)
-  __shared__ float4 s_x[FB * XS4];
+  // LDS budget (1,280-byte granules: 160 KB / 128): with two live triples 2,816 + 768 + 1,536 + 128 + 2,304 (table) = 7,552 bytes = six
+  // granules = 21 waves per CU, so that the registers' five waves per SIMD fit (8,080 bytes took seven: 18 waves per CU)
+  constexpr int RW_FLOATS = (WAVE * FX_LROW > FX_BASE2 + 2 * FX_TRI2) ? WAVE * FX_LROW : FX_BASE2 + 2 * FX_TRI2;
+  __shared__ __attribute__((aligned(16))) float s_rw[RW_FLOATS];  // hop 1: 64 x FX_LROW; hop 2: base [0, 320) + two triples [320, 704)
+  constexpr int XS2 = CL > 0 ? (CL + 1) / 2 : 1;  // float2s per survivor row of live channel colours
+  __shared__ float2 s_x[FB * XS2];
   __shared__ float4 s0[FB], s1[FB], s2[FB];
-  __shared__ uint32_t s_id[FB + 4];
+  __shared__ uint32_t s_id[FB];
   extern __shared__ __attribute__((aligned(16))) float s_dx[];  // [live channel][c = pixel & 15][q = pixel >> 4]
-  static_assert(FX_BASE2 + 2 * FX_TRI2 <= WAVE * FX_LROW, "second-hop regions must fit the transposition buffer");
+  static_assert(FX_LROW % 2 == 0 && FX_LROW >= 8, "hop 1 stores four (r, w) pairs per lane, read back as float2");
   const unsigned long long trace_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   const int omode = tile_order_mode(a.order);
@@ -954,14 +970,14 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
   constexpr bool FULL_ROWS = FX_FULL_ROWS;
   struct Row {
     float4 g0, g1, g2;
-    float4 x[XS4];
+    float2 x[XS2];
     int k;
   };
   auto fetch_rest = [&](Row &r) {
     r.g2 = s2[r.k];
     if (CL > 0) {
 #pragma unroll
-      for (int c = 0; c < XS4; c++) r.x[c] = s_x[r.k * XS4 + c];
+      for (int c = 0; c < XS2; c++) r.x[c] = s_x[r.k * XS2 + c];
     }
   };
   auto fetch = [&](Row &r, int k) {  // (a row beyond the last survivor is stale LDS: read, never used)
@@ -1000,7 +1016,7 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
         s_id[sl] = id;
         if (CL > 0) {  // the LIVE triples of the Gaussian's channel row only
           const float *xs = a.extra + (size_t)id * CE;
-          float *dst = reinterpret_cast<float *>(&s_x[sl * XS4]);
+          float *dst = reinterpret_cast<float *>(&s_x[sl * XS2]);
 #pragma unroll
           for (int j = 0; j < NL; j++) {
             const float *t3 = xs + 3u * live_t[j];
@@ -1045,10 +1061,7 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
             const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
             float e = r.g2.x * dpix0 + r.g2.y * dpix1 + r.g2.z * dpix2 + r.g2.w * ddep + dalp;
 #pragma unroll
-            for (int c = 0; c < CL; c++) {
-              const float4 v = r.x[c / 4];
-              e += (c % 4 == 0 ? v.x : (c % 4 == 1 ? v.y : (c % 4 == 2 ? v.z : v.w))) * dxp[c];
-            }
+            for (int c = 0; c < CL; c++) e += (c % 2 == 0 ? r.x[c / 2].x : r.x[c / 2].y) * dxp[c];
             const float dL_dalpha = Tn * e - (X + Tb) * rc;
             X += w * e;
             T = Tn;
@@ -1073,12 +1086,12 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
         }
         if (anyhit) {  // wave-uniform
           const bool row_live = ((anyhit >> row) & 1u) && (g + row < m);
-          const uint32_t gid = row_live ? s_id[g + row] : 0u;
+          const uint32_t gid = row_live ? s_id[min(g + row, FB - 1)] : 0u;
           const float2 gxy = *reinterpret_cast<const float2 *>(&s0[min(g + row, FB - 1)]);  // this row's Gaussian centre
           const float dxr = gxy.x - pxf;                                                      // against this lane's column
           // ---- hop 1: (r, w) of the four Gaussians, pixel lanes -> reducer lanes (row = Gaussian, c = lane & 15)
-          *reinterpret_cast<float4 *>(&s_rw[lane * FX_LROW]) = make_float4(accr[0], accw[0], accr[1], accw[1]);
-          *reinterpret_cast<float4 *>(&s_rw[lane * FX_LROW + 4]) = make_float4(accr[2], accw[2], accr[3], accw[3]);
+#pragma unroll
+          for (int u = 0; u < 4; u++) *reinterpret_cast<float2 *>(&s_rw[lane * FX_LROW + 2 * u]) = make_float2(accr[u], accw[u]);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -41,7 +41,41 @@ def report(name, rec, length_of):
                   f"started at median {np.median(late[sel]):5.1f} us")
 
 
+def c3_main():
+    """SCENE=c3: the headline workload (200k Gaussians, SH3, 1024^2, alpha-mask loss) through the raw bindings."""
+    from mygauhuman_amd import synthetic
+    from mygauhuman_amd.diff_gaussian_rasterization import _C
+    P, W, H = 200000, 1024, 1024
+    cam, g = synthetic.uniform_scene(P, W, H, seed=0, sh_degree=3)
+    t = {k: torch.from_numpy(v).cuda() for k, v in g.items() if isinstance(v, np.ndarray)}
+    view, proj, campos = (torch.from_numpy(cam[k]).cuda() for k in ("viewmatrix", "projmatrix", "campos"))
+    bg, e = torch.zeros(3, device="cuda"), torch.empty(0)
+
+    def step():
+        o = _C.rasterize_gaussians(bg, t["means3D"], e, t["opacities"], t["scales"], t["rotations"], 1.0, e, view, proj, cam["tanfovx"],
+                                   cam["tanfovy"], H, W, t["shs"], 3, campos, False, False)
+        R, color, depth, alpha, radii, gb, bb, ib = o
+        dc = torch.sign(color - 0.5) / color.numel()
+        _C.rasterize_gaussians_backward(bg, t["means3D"], radii, e, t["scales"], t["rotations"], 1.0, e, view, proj, cam["tanfovx"],
+                                        cam["tanfovy"], dc, torch.zeros_like(alpha), 0.2 * (alpha - 0.5) / alpha.numel(), t["shs"], 3, campos,
+                                        gb, R, bb, ib, alpha, False)
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    words = 2 * 16 * 5120
+    buf = torch.zeros(words, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib.gsr_debug_wave_trace(buf.data_ptr(), words), "trace")
+    step()
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib.gsr_debug_wave_trace(None, 0), "trace")
+    rec = buf.cpu().numpy().view(np.uint64).reshape(2, -1, 4)
+    report("blend forward (C3)", rec[0], lambda r: np.maximum(r[:, 2].astype(np.int64), 1))
+    report("blend backward (C3)", rec[1], lambda r: np.maximum((r[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64), 1))
+
+
 def main():
+    if os.environ.get("SCENE") == "c3":
+        return c3_main()
     import render_bench
     if os.environ.get("SCENE", "render_bench") == "bench":   # the frame of bench.py's render_200k lines
         import bench
