@@ -215,7 +215,7 @@ __global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_k
     // (two register sets, A and B, used in turn -- an explicit 2x unroll: a rotating single set costs ~30 v_mov per survivor)
     // FWD_FULL_ROWS: whole rows travel ahead (no exposed LDS round trip; 32 registers per set with 18 channels).  Otherwise only the
     // cut-off rows do, and a contributing survivor fetches its colour + channel rows in one round trip (16 registers less per set).
-    constexpr bool FULL = FWD_FULL_ROWS || CE == 0;
+    constexpr bool FULL = FWD_FULL_ROWS;
     struct Row {
       float4 g0, g1, g2;
       float2 x[XS2];
