@@ -440,10 +440,36 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
     // List segments (gsr_common.h): a list much longer than the frame's mean is cut into pieces of about the mean length, each with
     // a visiting slot of its own (sorted by the PIECE's length) and the tile's checkpoint records reserved here.  "Much longer" =
     // at least 1.5 x max(mean over the busy tiles, 256): a uniform cloud (C3: lists 150..355) cuts nothing.
+    //
+    // Tail cut (segments >> 8 = sixteenths of the busy tiles, Options::blend_tail_cut): the lists that are visited LAST are cut in two
+    // as well.  A blend wave is a large unit of work -- at C3 the backward is 2.7 rounds of ~75 us waves -- and the kernel ends with a
+    // tail in which the last-started waves run among idle SIMDs (tools/wave_trace.py: 15 % of the span).  Half-length pieces at the
+    // end of the order halve that tail; the forward of a cut tile only pays the checkpoint stores.
     __syncthreads();
     const uint32_t target = max(s_busy ? s_kept / s_busy : 0u, 256u), extra_cap = seg_extra_max((uint32_t)tiles);
     const float cls_scale = (float)(NCLS - 2) / (float)mxn;
+    const uint32_t outlier = (uint32_t)segments & 0xFFu, tail16 = ((uint32_t)segments >> 8) & 0xFFu;
     uint32_t mycls[PER_MAX], mycls0[PER_MAX], mysegs[PER_MAX];
+    // (classes by a float multiply: the order of near-equal lengths is of no consequence, a 64-bit division per tile is)
+#pragma unroll
+    for (int k = 0; k < PER_MAX; k++) {
+      const int t = t0 + k;
+      mycls0[k] = 0u;
+      if (k < per && t < tiles) {
+        mycls0[k] = cnt[k] == 0u ? 0u : 1u + min((uint32_t)(NCLS - 2), (uint32_t)((float)cnt[k] * cls_scale));  // 1 .. NCLS - 1
+        if (tail16) atomicAdd(&s_ccount[mycls0[k]], 1u);
+      }
+    }
+    uint32_t late_from = 0xFFFFFFFFu;
+    if (tail16) {  // where every class of whole lists starts in the visiting order: the classes from `late_from` on are cut
+      __syncthreads();
+      if (wave == 0) {
+        const uint32_t v = s_ccount[NCLS - 1 - lane];
+        s_cbase[NCLS - 1 - lane] = wave_incl_scan(v) - v;
+      }
+      __syncthreads();
+      late_from = s_busy - min(s_busy, (s_busy * tail16) / 16u);
+    }
 #pragma unroll
     for (int k = 0; k < PER_MAX; k++) {
       const int t = t0 + k;
@@ -452,20 +478,30 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
       if (k < per && t < tiles) {
         const uint32_t n = cnt[k];
         uint32_t nseg = 1u;
-        if (segments && 4u * n >= (uint32_t)segments * target) {  // (segments = the outlier threshold in quarters of the mean)
+        if (outlier && 4u * n >= outlier * target)  // (the outlier threshold in quarters of the mean)
           nseg = max(2u, min((uint32_t)SEG_MAX, (n + target / 2u) / target));
-          if (atomicAdd(&s_extra, nseg - 1u) + (nseg - 1u) > extra_cap) nseg = 1u;  // the frame's extra slots are used up: walked whole
-        }
+        else if (tail16 && n >= 2u * WAVE && s_cbase[mycls0[k]] >= late_from)
+          nseg = 2u;
+        if (nseg > 1u && atomicAdd(&s_extra, nseg - 1u) + (nseg - 1u) > extra_cap) nseg = 1u;  // the frame's extra slots are used up: walked whole
         if (nseg > 1u) ckpt_base[t] = atomicAdd(&s_rec, nseg);  // (<= 2 records per extra slot: inside ckpt_records())
         // a cut tile's FIRST slot stays in the class of the whole list -- the forward walks the list whole from that slot and must
         // start as early as before; the other pieces are sorted by the piece's length
-        // (classes by a float multiply: the order of near-equal lengths is of no consequence, a 64-bit division per tile is)
-        mycls0[k] = n == 0u ? 0u : 1u + min((uint32_t)(NCLS - 2), (uint32_t)((float)n * cls_scale));  // 1 .. NCLS - 1
         mycls[k] = mycls0[k];
         if (nseg > 1u) mycls[k] = 1u + min((uint32_t)(NCLS - 2), (uint32_t)((float)segment_len((int)n, (int)nseg) * cls_scale));
         mysegs[k] = nseg;
+      }
+    }
+    if (tail16) {  // count again, now with the pieces
+      __syncthreads();
+      if ((int)threadIdx.x < NCLS) s_ccount[threadIdx.x] = 0u;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < PER_MAX; k++) {
+      const int t = t0 + k;
+      if (k < per && t < tiles) {
         atomicAdd(&s_ccount[mycls0[k]], 1u);
-        if (nseg > 1u) atomicAdd(&s_ccount[mycls[k]], nseg - 1u);
+        if (mysegs[k] > 1u) atomicAdd(&s_ccount[mycls[k]], mysegs[k] - 1u);
       }
     }
     __syncthreads();

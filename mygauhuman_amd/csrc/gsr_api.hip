@@ -124,6 +124,9 @@ static int set_option(Options &o, const char *key, int v) {
   } else if (!strcmp(key, "blend_layout")) {
     if (v != 0 && v != 1) return bad("0 (quadrant waves) or 1 (4x4 blocks, four survivors per step)");
     o.blend_layout = v;
+  } else if (!strcmp(key, "blend_tail_cut")) {
+    if (v < 0 || v > 16) return bad("0 .. 16 (sixteenths of the busy tiles at the end of the visiting order)");
+    o.blend_tail_cut = v;
   } else if (!strcmp(key, "blend_segments")) {
     if (v < 0 || v > 64) return bad("0 (never) or the outlier threshold in quarters of the frame's mean list length (4 .. 64)");
     o.blend_segments = v;
@@ -421,7 +424,7 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   if (R_host < 0 || opt.binning_mode == GSR_BINNING_TILE_BUCKET) {
     // list segments need the forward variant that writes the checkpoints (blend_forward_kernel<1, .>)
     const int segments = (opt.tile_order == 1 && opt.blend_layout == 0 && !opt.blend_fwd_dma && (in.n_extra != 0 || opt.blend_fwd_waves == 4))
-                             ? opt.blend_segments : 0;
+                             ? (opt.blend_segments | (opt.blend_tail_cut << 8)) : 0;
     rc = bucket_binning(geom, radii, in.P, grid_x, grid_y, capacity, R_host < 0, bin, img.ranges, img.order, img.ckpt_base, segments,
                         dev_status, in.prefiltered != 0, scan_fused, opt, stream, in.debug & 1);
     if (rc != GSR_OK) return rc;

@@ -245,6 +245,8 @@ struct Options {
   int blend_bwd_reduce = 3;  // 3 LDS folds (default), 0 permlane / DPP folds, 1 MFMA on folded rows, 2 transposed MFMA contraction
   int deterministic = 0;     // backward: fixed-order reduction of the gradient rows instead of float atomics
   int blend_layout = 0;      // 0: a wave per 8x8 quadrant, one survivor at a time; 1: a wave per 4x4 block, four survivors per step (forward)
+  int blend_tail_cut = 0;    // sixteenths of the busy tiles, counted from the END of the visiting order, whose lists are cut in two as well
+                             // (measured at C3 with a pool of tiles / 4: 4/16 = +-0, 6/16 and 8/16 = -1 .. -3 %: off)
   int blend_segments = 8;    // > 0: lists of at least blend_segments / 4 x the frame's mean list are walked in segments by the backward
                              // (forward checkpoints), see ORDER_HDR; 0: never
   int blend_prio = 1;        // 1: blend waves take an issue priority from the length of their tile's list (list_priority)
