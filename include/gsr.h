@@ -70,9 +70,15 @@ int gsr_get_binning_mode(void);
  *   "bucket_hist" in {0, 1}: tile-bucket counting without global atomics (per-workgroup LDS histograms + a dense prefix table,
  *       default) or with one returning global atomic per instance (also taken for tile grids beyond 8192 tiles);
  *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the atomic variant;
- *   "tile_order" in {0, 1}: the order in which the blend kernels visit the tiles (tile-bucket back-end, histogram path): 1 =
+ *   "tile_order" in {0, 1, 2, 3}: the order in which the blend kernels visit the tiles (tile-bucket back-end, histogram path): 1 =
  *       longest list first, dealt round-robin to the XCDs (default), 0 = the natural order (a contiguous band of tile rows per
- *       XCD); results do not depend on it;
+ *       XCD), 2 / 3 = blocks of 2 x 2 / 4 x 2 tiles by summed length, a block per XCD; results do not depend on it;
+ *   "blend_segments" in 0 .. 64: 0 = every list is walked whole by the backward; v > 0 (default 8) = a list of at least v / 4 times
+ *       the frame's mean list is walked in up to four segments by different waves, each started from a checkpoint of the blend
+ *       state the forward writes at the segment boundary (gradients agree with the whole walk to rounding; needs tile_order 1);
+ *   "blend_tail_cut" in 0 .. 16 (default 0), "blend_prio" in {0, 1} (default 1; 2..4 are MEASUREMENT ONLY and render wrong
+ *       images), "blend_layout" in {0, 1} (1 = experimental forward with a wave per 4x4 pixel block), "blend_fwd_dma" in {0, 1}:
+ *       documented experiments, see DESIGN.md section 4;
  *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above);
  *   "deterministic" in {0, 1}: the backward reduces its per-(Gaussian, tile-quadrant) partial sums in a fixed order instead of
  *       with float atomics: run-to-run bit-identical gradients (for tests; costs a 256-byte slot per instance quadrant).
