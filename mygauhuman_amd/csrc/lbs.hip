@@ -409,7 +409,10 @@ struct LbsBwdArgs {
   float *partials;  // [workgroups][24 * 12] per-workgroup dA_pose sums (no atomics) or null
 };
 
-__global__ __launch_bounds__(LBS_BLOCK) void lbs_backward_kernel(const LbsBwdArgs a) {
+// (amdgpu_waves_per_eu(4): the allocator stopped at 132 VGPRs = three waves per SIMD where the 40 KB of LDS admit four; at 128 with
+// four spilled registers the kernel takes 25.6 instead of 32.9 us in the render() frame.  The same hint on the forward kernel -- 108
+// VGPRs, asked for 80 -- spills in the search loop: 76 instead of 54 us.)
+__global__ __launch_bounds__(LBS_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void lbs_backward_kernel(const LbsBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sAb[NJ * 16], sAp[NJ * 16];
   constexpr int ROW = NJ + 12 + 1;                // bw[24] | g_Ap[12] | pad (odd stride: conflict-free column reads)
   __shared__ float s_rows[LBS_BLOCK * ROW];       // per-point operands of the workgroup-level dA_pose product
