@@ -25,6 +25,7 @@
 
 namespace gsr {
 
+constexpr int SORT_WAVE_MAX = 512;   // longest list one wave sorts by itself (8 runs of 64 + rank merge); longer ones: bucket_sort_kernel
 constexpr int SORT_BIG = 2048;  // keys the workgroup sort of lists > 512 handles in LDS (two buffers of 16 KB); longer lists: chunks + global merge
 
 // One returning atomic per instance: the value it returns is the instance's arrival rank inside its tile, kept in
@@ -317,13 +318,13 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
                                                                 const uint32_t *totals, const uint32_t *table, const uint32_t *rank,
                                                                 const uint32_t *gids, uint64_t *bucket, uint32_t capacity,
                                                                 uint2 *ranges, uint32_t *status, int check_prefilter, uint32_t *order, int order_mode,
-                                                                int grid_x, uint32_t *ckpt_base, int segments) {
+                                                                int grid_x, uint32_t *ckpt_base, int segments, uint32_t *big_list) {
   constexpr int PER_MAX = (HIST_MAX_TILES + HB - 1) / HB;
   __shared__ uint32_t s_base[HIST_MAX_TILES];
   __shared__ uint32_t s_wtot[HB / WAVE];
   const uint32_t R = *g.total;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    g.total[2] = 0;  // work-list counter of the sort kernels that follow
+    if (R > capacity) g.total[2] = 0;  // work-list counter of the long-list sort (otherwise written by the order builder below)
     if (status) {
       status[0] = R;
       status[1] = (R > capacity ? 1u : 0u) | ((check_prefilter && g.total[1]) ? 2u : 0u);
@@ -378,6 +379,20 @@ __global__ __launch_bounds__(HB) void bucket_scatter_hist_kernel(const GeomState
       bucket[s_base[r >> 16] + (r & 0xFFFFu)] = ((uint64_t)dbits << 32) | (uint64_t)gid;
     }
     return;
+  }
+  // ---- work list of the long-list sort (this workgroup sees every list length): written HERE, not by 4,096 wave-sort workgroups
+  // with a global atomic each
+  {
+    __shared__ uint32_t s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_MAX; k++) {
+      const int t = t0 + k;
+      if (k < per && t < tiles && cnt[k] > (uint32_t)SORT_WAVE_MAX) big_list[atomicAdd(&s_nbig, 1u)] = (uint32_t)t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) g.total[2] = s_nbig;
   }
   // ---- visiting order of the tiles for the blend kernels (built by the extra workgroup): the tiles with the longest lists go
   // FIRST, dealt round-robin to the eight XCDs (tile_order_mode / ordered_item4 in gsr_common.h).  A wave walks its list
@@ -692,7 +707,6 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t *b, int n, uint32_
   }
 }
 
-constexpr int SORT_WAVE_MAX = 512;   // longest list one wave sorts by itself (8 runs of 64 + rank merge); longer ones: bucket_sort_kernel
 
 // ---- sort by runs + rank merge (lists of 65 .. 512 keys) ---------------------------------------------------------------
 // A full bitonic network over NREG x 64 keys costs log^2 stages over every register and needs a power-of-two size: a tile with
@@ -778,8 +792,8 @@ __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ran
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const uint2 r = ranges[tile];
   const int n = (int)(r.y - r.x);
-  if (n > SORT_WAVE_MAX) {  // left to bucket_sort_kernel: onto its work lists (any order: every tile is sorted by itself)
-    if (lane == 0) big_list[atomicAdd(big_count, 1u)] = tile;
+  if (n > SORT_WAVE_MAX) {  // left to bucket_sort_kernel: onto its work list unless the scatter kernel already built it (big_list null)
+    if (big_list && lane == 0) big_list[atomicAdd(big_count, 1u)] = tile;
     return;
   }
   if (n == 0) return;
@@ -1043,7 +1057,7 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
     }
     hipLaunchKernelGGL(bucket_scatter_hist_kernel, dim3(n_sb + 1), dim3(HB), 0, stream, g, wg_start, (int)tiles, b.tile_counts, table,
                        b.vals_a, b.vals_s, b.keys_a, cap32, ranges, dev_status, check_prefilter ? 1 : 0, order, opt.tile_order, grid_x,
-                       ckpt_base, segments);
+                       ckpt_base, segments, b.tile_cursor);
     GSR_LAUNCH_CHECK(stream, debug);
   } else {
     const int CSTRIDE = opt.bucket_cstride;
@@ -1063,9 +1077,13 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
                        b.tile_cursor, b.vals_a, b.keys_a, cap32);
     GSR_LAUNCH_CHECK(stream, debug);
   }
-  // work list of the long lists: tile_cursor is free by now (the scatter kernels are its last readers), total[2] was zeroed by them
+  // The two sort kernels.  Work list of the long lists in tile_cursor (free by now: the scatter kernels are its last readers), its
+  // counter in total[2]: written by the scatter kernel's order builder on the histogram path, by the wave sort on the atomic path.
+  // (Measured and dropped: the long-list sort on a side stream NEXT TO the wave sort, fork / join by events -- the kernels are
+  // independent once the list is built up front.  The two event dependencies cost more than the overlap gains on this runtime: C3
+  // binning 61 -> 71..77 us, render() as one graph 0.803 -> 0.836 ms.)
   hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, stream, ranges, b.keys_a, b.vals_s, b.keys_s,
-                     b.tile_cursor, g.total + 2);
+                     hist ? (uint32_t *)nullptr : b.tile_cursor, g.total + 2);
   GSR_LAUNCH_CHECK(stream, debug);
   // (a separate 16 KB-LDS instantiation for 1025..2048 keys was measured: slower -- the register sorts of the runs, not the
   // LDS occupancy, bound this kernel)
