@@ -163,8 +163,34 @@ __device__ __forceinline__ int grid_nearest(const char *ws, const float *q, floa
   const float eps = 1e-3f * h;  // slack for the rounding of the cell assignment
   float best = FLT_MAX;
   int bid = 0x7fffffff;
-  for (int r = 0; r <= rmax; r++) {
-    if (r >= 2) {
+  // Rings 0 and 1 in one go: the nine (z, y) rows around q's cell, each ONE contiguous run of the sorted list over x in
+  // [c0 - 1, c0 + 1].  All eighteen run bounds are requested before any vertex is looked at: ring by ring (1 + 10 runs, each a
+  // pair of dependent loads in front of its vertices) the search was a chain of ~22 memory round trips per point.
+  {
+    uint32_t rb[9], re[9];
+    const int xa = max(c0 - 1, 0), xb = min(c0 + 1, d0 - 1);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const int z = c2 + j / 3 - 1, y = c1 + j % 3 - 1;
+      const bool in = z >= 0 && z < d2 && y >= 0 && y < d1;
+      const int row = ((in ? z : 0) * d1 + (in ? y : 0)) * d0;
+      rb[j] = cells[row + xa];
+      re[j] = in ? cells[row + xb + 1] : rb[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+      for (uint32_t i = rb[j]; i < re[j]; i++) {
+        const float4 v = sorted[i];
+        const float d = sqdist_exact(v.x, v.y, v.z, q);
+        const int id = __float_as_int(v.w);
+        if (d < best || (d == best && id < bid)) {
+          best = d;
+          bid = id;
+        }
+      }
+  }
+  for (int r = 2; r <= rmax; r++) {
+    {
       const float lb = (float)(r - 1) * h - eps;
       if (best < lb * lb) break;
     }
