@@ -1198,6 +1198,8 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
 
 // one kernel per number of live triples, each told how many waves per SIMD its registers should leave room for (the register
 // allocator then fits 96 / 128 VGPRs instead of stopping two registers above the step)
+// (five and six live triples: the gradient table makes 11.1 / 12.2 KB of LDS = 9 / 10 granules = three waves per SIMD whatever the
+// registers do, so the allocator is told three and keeps everything in registers -- asked for four it spilled)
 #define GSR_FEATURES_KERNEL(NL, WAVES)                                                                                        \
   __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void blend_backward_features_kernel_##NL( \
       const BlendBwdArgs a) {                                                                                                 \
@@ -1208,8 +1210,8 @@ GSR_FEATURES_KERNEL(1, 5)
 GSR_FEATURES_KERNEL(2, 5)
 GSR_FEATURES_KERNEL(3, 4)
 GSR_FEATURES_KERNEL(4, 4)
-GSR_FEATURES_KERNEL(5, 4)
-GSR_FEATURES_KERNEL(6, 4)
+GSR_FEATURES_KERNEL(5, 3)
+GSR_FEATURES_KERNEL(6, 3)
 #undef GSR_FEATURES_KERNEL
 
 int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t stream) {
