@@ -49,10 +49,10 @@ __global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_k
   constexpr uint32_t H = SLOTS == 1 ? 4 / WPG : 1;  // workgroups per tile
   const uint32_t wv = threadIdx.x / WAVE;
   constexpr int WPT = 4 / SLOTS;  // waves per tile
-  // survivors' extra channels: rows of XS2 float2 (72 bytes for 18 channels: with the records' 48 that is 30.7 KB per workgroup, five
-  // workgroups per CU -- padded to 80 bytes for whole 16-byte reads it is 32.8 KB and four)
-  constexpr int XS2 = CE > 0 ? CE / 2 : 1;
-  __shared__ float2 s_x_all[CE > 0 ? WPG * WAVE * XS2 : 1];
+  // survivors' extra channels: rows of XS2 float2, padded to whole 16-byte reads (18 channels: 80 bytes, five ds_read_b128 instead of
+  // nine ds_read_b64 per contributing survivor); with two-wave workgroups the 8 bytes per row cost no resident wave
+  constexpr int XS2 = CE > 0 ? (CE + 3) / 4 * 2 : 1;
+  __shared__ __attribute__((aligned(16))) float2 s_x_all[CE > 0 ? WPG * WAVE * XS2 : 1];
   __shared__ float4 s0_all[WPG * WAVE];     // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
   // what the cut-off test needs sits in s0 + the first half of s1, what only a blending survivor needs in the second half of s1 +
   // s2: each branch's LDS reads are whole 8- / 16-byte accesses (a 4-byte broadcast read costs as many LDS cycles as an 8-byte one,
@@ -218,15 +218,15 @@ __global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_k
     constexpr bool FULL = FWD_FULL_ROWS;
     struct Row {
       float4 g0, g1, g2;
-      float2 x[XS2];
+      float4 x[XS2 > 1 ? XS2 / 2 : 1];
       int kk;
     };
     auto fetch_rest = [&](Row &r) {
       r.g2 = s2[r.kk];
       if (CE > 0) {
-        const float2 *xr = &s_x[r.kk * XS2];
+        const float4 *xr = reinterpret_cast<const float4 *>(&s_x[r.kk * XS2]);
 #pragma unroll
-        for (int c = 0; c < XS2; c++) r.x[c] = xr[c];
+        for (int c = 0; c < XS2 / 2; c++) r.x[c] = xr[c];
       }
     };
     auto fetch = [&](Row &r, int k) {  // (a row beyond the last survivor is stale LDS: read, never used)
@@ -258,7 +258,10 @@ __global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_k
           Wt[s] += w;
           if (CE > 0) {
 #pragma unroll
-            for (int c = 0; c < CE; c++) X[s][c] += (c % 2 == 0 ? r.x[c / 2].x : r.x[c / 2].y) * w;
+            for (int c = 0; c < CE; c++) {
+              const float4 v = r.x[c / 4];
+              X[s][c] += (c % 4 == 0 ? v.x : (c % 4 == 1 ? v.y : (c % 4 == 2 ? v.z : v.w))) * w;
+            }
           }
           T[s] = blend ? test_T : T[s];
           last[s] = blend ? __float_as_uint(r.g1.z) : last[s];
