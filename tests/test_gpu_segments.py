@@ -119,3 +119,37 @@ def test_segmented_feature_backward_equals_whole_walk(used, no_segments):
         assert torch.equal(a, b)
     for k in grads[True]:
         util.assert_close(k, grads[True][k], grads[False][k], tol=2e-5, max_bad_frac=1e-4, outer_tol=2e-4)
+
+
+def test_tail_cut_segments_equal_whole_walk(oracle):
+    """Knob blend_tail_cut (default off): the lists visited LAST are cut in two as well, in a uniform scene that cuts nothing by
+    itself.  Same checks as above: the order really has the pieces, the gradients are those of the whole-list walk and of the oracle."""
+    from mygauhuman_amd import _lib
+    P, W, H = 6000, 160, 128
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    cam, g = util.make_scene(P, W, H, 41, 2, 0.03, 0.0)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    rng = np.random.default_rng(5)
+    ref = util.oracle_forward(oracle, cam, g, bg, "sh")
+    solid = ref["img"]["fragile"] == 0
+    dc = (rng.normal(0, 1, (3, H, W)) * solid).astype(np.float32)
+    dd = (rng.normal(0, 1, (1, H, W)) * solid).astype(np.float32)
+    da = (rng.normal(0, 1, (1, H, W)) * solid).astype(np.float32)
+    want = oracle.rasterize_backward(ref, dc, dd, da)
+    res = {}
+    try:
+        for cut in (8, 0):
+            _lib.set_tuning("blend_tail_cut", cut)
+            f = util.hip_forward(cam, g, bg, "sh", debug=True)
+            omode, slots, entries = _order(f, tiles)
+            nseg = ((entries >> 25) & 7) + 1
+            if cut:
+                assert omode == 1 and slots > tiles and nseg.max() == 2, (slots, tiles, int(nseg.max()))
+            else:
+                assert slots == tiles and nseg.max() == 1
+            res[cut] = util.hip_backward(f, dc, dd, da, debug=True)
+    finally:
+        _lib.set_tuning("blend_tail_cut", 0)
+    for n in ("dL_dmean2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        util.assert_close(n + " (tail cut vs whole walk)", res[8][n], res[0][n], tol=2e-5, max_bad_frac=1e-4, outer_tol=2e-4)
+        util.assert_close(n + " (tail cut vs oracle)", res[8][n].reshape(want[n].shape), want[n], tol=1e-4, max_bad_frac=2e-4)
