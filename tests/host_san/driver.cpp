@@ -70,6 +70,25 @@ static void check_carving() {
       if (i) EXPECT(static_cast<const char *>(starts[i - 1]) + sizes[i - 1] <= s);
     }
   }
+  // order entries and list segments (gsr_common.h "list segments"): the packing round-trips, never looks like the padding entry, and
+  // the segment arithmetic the forward (checkpoints) and the backward (walk bounds) share covers a list exactly once
+  for (uint32_t tile : {0u, 1u, 4095u, 8191u, ORDER_TILE_MASK})
+    for (uint32_t nseg = 1; nseg <= (uint32_t)SEG_MAX; nseg++)
+      for (uint32_t seg = 0; seg < nseg; seg++) {
+        const uint32_t e = order_entry(tile, seg, nseg);
+        EXPECT(e != ORDER_NO_TILE && order_entry_tile(e) == tile && order_entry_seg(e) == seg && order_entry_nseg(e) == nseg);
+      }
+  for (int n : {1, 63, 64, 65, 384, 385, 511, 512, 704, 896, 897, 1000, 1398, 2047, 2048, 4097, 100000})
+    for (int nseg = 1; nseg <= SEG_MAX; nseg++) {
+      const int len = segment_len(n, nseg);
+      EXPECT(len % 64 == 0 && len >= (n + nseg - 1) / nseg && (long)len * nseg >= n);
+      long covered = 0;
+      for (int sgm = 0; sgm < nseg; sgm++) {
+        const int lo = sgm * len, hi = lo + len < n ? lo + len : n;
+        if (lo < n) covered += hi - lo;   // (a segment that starts beyond the list is empty: the kernels return at once)
+      }
+      EXPECT(covered == n);
+    }
   const int dims[][2] = {{1, 1}, {16, 16}, {17, 33}, {160, 96}, {512, 512}, {1024, 1024}, {1920, 1080}, {4096, 4096},
                          {16, 400}, {16, 16000}, {16000, 16}, {48, 7000}, {33, 33}};
   const size_t Rs[] = {0, 1, 4095, 4096, 4097, 1326873, 5000000};
