@@ -32,6 +32,19 @@ def pytest_configure(config):
     _install_native_backtrace()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _stress_tuning():
+    """GSR_TEST_TUNING="key=value,key=value": process-default tuning knobs for the whole run, e.g. "blend_segments=4,blend_tail_cut=8"
+    to push every long enough list of the parity tests through the segmented backward (tests that pin a knob themselves still do)."""
+    spec = os.environ.get("GSR_TEST_TUNING", "")
+    if spec:
+        from mygauhuman_amd import _lib
+        for kv in spec.split(","):
+            k, v = kv.split("=")
+            _lib.set_tuning(k.strip(), int(v))
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc
