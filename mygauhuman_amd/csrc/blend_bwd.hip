@@ -1141,8 +1141,6 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
           };
 #pragma unroll
           for (int j0 = 0; j0 < NL; j0 += 2) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int npair = j0 + 1 < NL ? 2 : 1;
 #pragma unroll
             for (int jj2 = 0; jj2 < 2; jj2++) {
