@@ -97,7 +97,8 @@ int gsr_clear_stream_tuning(gsr_stream_t stream);
 int gsr_profile_enable(unsigned stage_mask);
 /* Measurement only: while a zero-filled device buffer is registered here, every wave of the blend kernels (default variants)
  * leaves {start, end} in 100 MHz ticks + its list length: forward waves in the first half of the buffer (4 words per wave,
- * wave index = workgroup * 4 + wave), backward waves in the second half.  words >= 2 * 16 * visiting slots; NULL switches it off. */
+ * wave index = workgroup * 4 + wave), backward waves in the second half.  words >= 2 * 16 * visiting slots of the image (32 * (4 * tiles
+ * + 64) always suffices; a rasterizer call that finds the buffer too small fails with GSR_EINVAL); NULL switches it off. */
 int gsr_debug_wave_trace(unsigned long long *device_buffer, size_t words);
 int gsr_profile_reset(void);
 int gsr_profile_read(int stage, double *total_ms, long *launches);

@@ -473,7 +473,12 @@ int forward_stage_b(const FwdIn &in, const GeomState &geom, BinningState &bin, c
   {  // (first half of the trace buffer: forward waves, 4 words each; second half: backward waves)
     ApiState &st = S();
     const size_t need = (size_t)tile_slots_max(grid_x, grid_y) * 4u * 4u;
-    fa.trace = st.trace_words.load() / 2 >= need ? st.trace.load() : nullptr;
+    fa.trace = st.trace.load();
+    if (fa.trace && st.trace_words.load() / 2 < need) {
+      set_error("gsr_debug_wave_trace: the registered buffer holds %zu words, this image needs %zu (2 x 16 x visiting slots)",
+                st.trace_words.load(), 2 * need);
+      return GSR_EINVAL;
+    }
   }
   fa.out_extra = in.out_extra;
   prof_begin(PROF_BLEND_FWD, stream);
@@ -707,7 +712,12 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
   {
     ApiState &st = S();
     const size_t need = (size_t)tile_slots_max(ba.grid_x, ba.grid_y) * 4u * 4u;
-    ba.trace = st.trace_words.load() / 2 >= need ? st.trace.load() + st.trace_words.load() / 2 : nullptr;
+    ba.trace = st.trace.load() ? st.trace.load() + st.trace_words.load() / 2 : nullptr;
+    if (ba.trace && st.trace_words.load() / 2 < need) {
+      set_error("gsr_debug_wave_trace: the registered buffer holds %zu words, this image needs %zu (2 x 16 x visiting slots)",
+                st.trace_words.load(), 2 * need);
+      return GSR_EINVAL;
+    }
   }
   ba.radii = radii;
   ba.point_offsets = geom.point_offsets;
