@@ -16,7 +16,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 # every symbol include/gsr.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_debug_wave_trace",
+    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_debug_wave_trace", "gsr_debug_clock_probe",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
@@ -60,6 +60,8 @@ def _load():
     lib.gsr_set_stream_tuning.restype = lib.gsr_clear_stream_tuning.restype = C.c_int
     lib.gsr_profile_enable.argtypes = [C.c_uint]
     lib.gsr_debug_wave_trace.argtypes = [C.c_void_p, C.c_size_t]
+    lib.gsr_debug_clock_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gsr_debug_clock_probe.restype = C.c_int
     lib.gsr_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.gsr_mark_visible.argtypes = [C.c_int, fp, fp, fp, vp, vp]
     lib.gsr_rasterize_forward.argtypes = [
@@ -179,6 +181,34 @@ def profile_read():
         check(lib.gsr_profile_read(i, C.byref(ms), C.byref(n)), "gsr_profile_read")
         out[s] = (ms.value, n.value)
     return out
+
+
+def clock_probe(workgroups=1024, fmas=1 << 19, device=None):
+    """Shader clock of the device right now, in GHz (gsr_debug_clock_probe; blocks until the probe kernel has run: ~1 ms at the
+    default chain length).  Returns (clock from the FMA chain, median over the workgroups; clock from s_memtime or None when that
+    counter does not tick with the shader clock)."""
+    import numpy as np
+    out = torch.zeros(2 * workgroups, dtype=torch.int64, device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    check(lib.gsr_debug_clock_probe(workgroups, fmas, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "gsr_debug_clock_probe")
+    v = out.cpu().numpy().reshape(workgroups, 2).astype(np.float64)
+    ticks = float(np.median(v[:, 0]))
+    ghz = 4.0 * fmas / (ticks * 10.0) if ticks > 0 else 0.0
+    mt = float(np.median(v[:, 1])) / (ticks * 10.0) if ticks > 0 else 0.0   # s_memtime ticks per ns
+    return ghz, (mt if mt > 0.5 else None)
+
+
+def settle_clock(device=None, max_ms=1500.0, tol=0.004, probe_fmas=1 << 19):
+    """Run the clock probe back to back until five consecutive readings agree within `tol` (or max_ms have passed): brings a GPU
+    that has just been handed to the process to the clock it sustains.  Returns the list of (ms since start, GHz) readings."""
+    import time
+    t0, hist = time.perf_counter(), []
+    while True:
+        ghz, _ = clock_probe(1024, probe_fmas, device)
+        ms = (time.perf_counter() - t0) * 1e3
+        hist.append((round(ms, 1), round(ghz, 4)))
+        last = [h[1] for h in hist[-5:]]
+        if (len(last) == 5 and max(last) - min(last) <= tol * max(last)) or ms > max_ms:
+            return hist
 
 
 def set_tuning(key, value, stream=None):

@@ -30,6 +30,7 @@ SOURCES = [
     ("ssim.hip", []),
     ("gemv.hip", []),
     ("loss.hip", []),
+    ("probe.hip", []),
     ("gsr_api.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -598,6 +598,313 @@ __global__ __launch_bounds__(WAVE) void blend_backward_kernel(const BlendBwdArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The plain pass as the library runs it by default (one wave per 8x8 quadrant, reductions through LDS): the design of the LFOLD
+// branch of blend_backward_kernel<1, 3, 0>, rewritten on its own after a census of that kernel's ISA against the measured cost of
+// every instruction class (round 4, DESIGN.md section 4 "Census").
+//
+// What the census said.  Rounds 2-3 read the kernel as bound by vector-instruction issue ("vector ALUs 99 % busy" -- with a factor
+// four cycles per instruction that this part does not have: a wave64 VALU instruction issues in two).  Taking 15 % of its VALU
+// instructions out changed nothing (191.8 -> 195.0 us, same box, interleaved): it is not.  Its busiest unit is the LDS ARRAY,
+// priced per wave-instruction by MI355X_MICROARCH.md (LDS): a 16-byte read costs 4 cycles even when every lane reads the same
+// address, a 12-byte read 8 (!), a 16-byte store 13, and one CU's four SIMDs share one array.  Per surviving (Gaussian, quadrant)
+// the round-3 kernel spent  12 (cut-off rows: b128 + b96) + 6 (colour row + opacity) + 70 / 4 (reduction per group of four: two
+// b128 stores 26, two read2_b64 16, second hop 16 + 8, id + centre 4) = 35.5 LDS cycles  -- 8,867 survivors per CU x 35.5 =
+// 315 k cycles = 132 of the kernel's 192 us at 2.39 GHz -- against ~100 cycles of VALU issue per SIMD.  Hence, here:
+//   * every survivor row is read in whole 16-byte words (cut-off test: two b128 = 8 cycles, opacity rides along; a contributing
+//     survivor: one b128 = 4), never as 12 bytes;
+//   * hop 1 of the reduction is PLANAR and lane-linear: plane (value u = r or w of Gaussian 0..3) x lane, written with eight
+//     ds_write_addtid_b32 (address = M0 + offset + 4 x lane: no address VGPR, 2 cycles each = 16 instead of 26), and the lane <->
+//     pixel assignment of the wave is chosen so that the four pixels a reducer lane sums are four CONSECUTIVE lanes:
+//         lane l:  c = l >> 2, q = l & 3  ->  pixel column lx = c & 7, row ly = 2 q + (c >> 3)
+//     so that reducer lane (row = Gaussian, c) fetches r and w of its pixels with two b128 reads (8 cycles instead of 16), free of
+//     bank conflicts (16 lanes x 16 bytes = the 64 banks);
+//   * 17.5 -> 13 LDS cycles per survivor in the reduction, 18 -> 12 in the walk: 25 instead of 35.5.
+// The instruction trims of the first rewrite stay (they cost nothing): row offsets in a VGPR the compiler cannot prove uniform
+// (no v_mov of a scalar address in front of every LDS read), zeros of a skipped survivor written in the skip path only, X and
+// T_final (bg . dL_dpix) as ONE state variable, dL_dalpha opening the dot product as an FMA, DEPTH = false (fused alpha-mask
+// loss) without the depth term, row-live from the hit bits alone, gradient-row byte offsets instead of ids in LDS and the atomic
+// in its scalar-base form, hardware reciprocals in the batch step's ellipse filter.
+// Same algorithm, same order of the floating-point sums in the reduction; the per-pixel recurrence rounds e and X + Tb differently
+// (within the 1e-4 contract; the deterministic kernel above is a different instantiation and unchanged).
+template <typename T>
+__device__ __forceinline__ T lds_at(const void *base, uint32_t byte_off) {
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+// the compiler narrows a 16-byte LDS read to the components it sees used before the next branch (12 bytes: twice the LDS cycles
+// of 16); naming the fourth component as an asm operand right after the load keeps the read whole
+__device__ __forceinline__ void keep_whole(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+template <bool DEPTH>
+__global__ __launch_bounds__(WAVE) void blend_backward_lds_kernel(const BlendBwdArgs a) {
+  // ONE block, laid out by hand: ids 256 + records 3 x 1,024 + reduction buffer 2,048 = 5,376 bytes (five 1,280-byte granules).
+  // The ids come FIRST: the reducer rows of a last, partial group read up to three words past the 64 ids -- into s0, never out of
+  // the allocation -- so the index needs no clamp.
+  constexpr uint32_t RW_BYTES = 8 * WAVE * 4;  // hop 1: eight planes x 64 lanes; hop 2 (320 floats) and the prologue reuse it
+  __shared__ __attribute__((aligned(16))) unsigned char lds[256 + 3 * 1024 + RW_BYTES];
+  uint32_t *s_id = reinterpret_cast<uint32_t *>(lds);      // Gaussian id x 64: the byte offset of its gradient row
+  float4 *s0 = reinterpret_cast<float4 *>(lds + 256);      // x, y, qa, qb      (qa = -conic_a log2(e)/2, qb = -conic_b log2(e))
+  float4 *s1 = reinterpret_cast<float4 *>(lds + 1280);     // qc, log2(255*opacity), front position (bits), opacity   (qc = -conic_c log2(e)/2)
+  float4 *s2 = reinterpret_cast<float4 *>(lds + 2304);     // r, g, b, depth
+  float *s_rw = reinterpret_cast<float *>(lds + 3328);
+  const uint32_t rw_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_rw);  // LDS byte address of the reduction buffer
+
+  const unsigned long long trace_t0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const int omode = tile_order_mode(a.order);
+  const uint32_t n_slots = tile_slots_of(a.order, a.grid_x, a.grid_y, omode);
+  const uint32_t item = omode ? ordered_item4(blockIdx.x, n_slots) : (blockIdx.x < n_slots * 4u ? xcd_remap_b(blockIdx.x, n_slots * 4u) : n_slots * 4u);
+  const uint32_t entry = tile_of_slot(a.order, omode, item / 4u, n_slots);
+  if (entry == ORDER_NO_TILE) return;  // (wave-uniform) padding slot, or beyond this frame's slots
+  const uint32_t tile = order_entry_tile(entry), seg = order_entry_seg(entry), nseg = order_entry_nseg(entry), part = item % 4u;
+  const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+  const uint32_t lane = threadIdx.x;
+  const uint2 range = a.ranges[tile];
+  const int n = (int)(range.y - range.x);
+  // this wave's SEGMENT of the list, front positions [s_lo, s_hi): the whole list unless the frame cut it (gsr_common.h "list segments")
+  const int seg_len = nseg > 1u ? segment_len(n, (int)nseg) : n;
+  const int s_lo = (int)seg * seg_len, s_hi = min(n, s_lo + seg_len);
+  if (seg != 0u && s_lo >= n) return;
+  list_priority(a.order, s_hi - s_lo, a.list_prio);
+  const size_t plane = (size_t)a.H * a.W;
+
+  // lane <-> pixel: c = lane >> 2, q = lane & 3 -> column c & 7, row 2 q + (c >> 3) of the quadrant (see above)
+  const uint32_t wc = lane >> 2, wq = lane & 3u;
+  const uint32_t lx = wc & 7u, ly = 2u * wq + (wc >> 3);
+  const int x0 = tx * TILE + (int)(part & 1u) * 8, y0 = ty * TILE + (int)(part >> 1) * 8;
+  const float rx0 = (float)x0, rx1 = (float)(x0 + 7), ry0 = (float)y0, ry1 = (float)(y0 + 7);
+  const int px = x0 + (int)lx, py = y0 + (int)ly;
+  const bool inside = px < a.W && py < a.H;
+  const int p = py * a.W + px;
+  const float pxf = (float)px, pyf = (float)py;
+  float T = inside ? a.final_T[p] : 0.f;
+  const int lastc = inside ? (int)a.n_contrib[p] : 0;
+  float dpix0 = 0.f, dpix1 = 0.f, dpix2 = 0.f, ddep = 0.f, dalp = 0.f;
+  if (a.loss_gt) {  // (kernel-uniform) fused alpha-mask loss: the pixel's gradient is formed here, see BlendBwdArgs
+    if (inside) {
+      const float d0 = a.loss_color[p] - a.loss_gt[p], d1 = a.loss_color[plane + p] - a.loss_gt[plane + p];
+      const float d2 = a.loss_color[2 * plane + p] - a.loss_gt[2 * plane + p];
+      dpix0 = d0 > 0.f ? a.loss_sc : (d0 < 0.f ? -a.loss_sc : 0.f);
+      dpix1 = d1 > 0.f ? a.loss_sc : (d1 < 0.f ? -a.loss_sc : 0.f);
+      dpix2 = d2 > 0.f ? a.loss_sc : (d2 < 0.f ? -a.loss_sc : 0.f);
+      dalp = a.loss_sa * (a.loss_alpha[p] - a.loss_mask[p]);
+    }
+  } else if (inside) {
+    dpix0 = a.dL_dpix[p];
+    dpix1 = a.dL_dpix[plane + p];
+    dpix2 = a.dL_dpix[2 * plane + p];
+    if (DEPTH) ddep = a.dL_ddepth[p];
+    dalp = a.dL_dalpha[p];
+  }
+  // XT = X + T_final (bg . dL_dpix): the suffix sum of w e and the background term only ever appear together
+  float XT = T * (a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2);
+  if (nseg > 1u) {  // (wave-uniform) start in the middle of the list: the forward's checkpoint at this segment's far boundary
+    const uint32_t fl = 8u * ly + lx;  // the forward's lane of this pixel (checkpoint planes are written in its layout)
+    const float *rb = a.ckpt + (size_t)(a.ckpt_base[tile] + seg) * (CKPT_PLANES * 256) + part * 64u + fl;
+    const float *rf = a.ckpt + (size_t)(a.ckpt_base[tile] + nseg - 1u) * (CKPT_PLANES * 256) + part * 64u + fl;
+    // what lies behind the boundary: sum_{k >= s_hi} w_k e_k = dL_dpix . (C_final - C_prefix(s_hi)), channel by channel
+    const float xb = dpix0 * (rf[256] - rb[256]) + dpix1 * (rf[512] - rb[512]) + dpix2 * (rf[768] - rb[768]) +
+                     ddep * (rf[1024] - rb[1024]) + dalp * (rf[1280] - rb[1280]);
+    XT += inside ? xb : 0.f;
+    T = inside ? rb[0] : 0.f;  // transmittance in front of entry s_hi (the final T for the last segment)
+  }
+  int maxlast = lastc;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxlast = max(maxlast, __shfl_xor(maxlast, d, WAVE));
+  // list entries at front positions >= maxlast contribute to none of this wave's pixels; walked from the back: idx = n - 1 - position
+  const int skip = max(n - maxlast, n - s_hi), walk_end = n - s_lo;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  // reducer side: lane (row = Gaussian of the group, kcol = lane & 15) sums the pixels of writer lanes 4 kcol .. 4 kcol + 3:
+  // column kcol & 7, rows 2 q + (kcol >> 3)
+  const uint32_t row = lane >> 4, kcol = lane & 15u;
+  const bool upper = (lane & 8u) != 0;
+  const uint32_t jj = lane & 7u;
+  const uint32_t rowbit = 1u << row, row16 = row * 16u;
+  const float hh = upper ? 1.f : 0.f;
+  const float colx = (float)(x0 + (int)jj), qtop = (float)y0;  // the reducer's pixel column; top pixel row of the quadrant
+  float dps[3][4];  // dL_dpix of the reducer's four pixels
+  s_rw[lane] = dpix0;
+  s_rw[WAVE + lane] = dpix1;
+  s_rw[2 * WAVE + lane] = dpix2;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) {
+    const float4 t4 = *reinterpret_cast<const float4 *>(&s_rw[ch * WAVE + kcol * 4u]);
+    dps[ch][0] = t4.x;
+    dps[ch][1] = t4.y;
+    dps[ch][2] = t4.z;
+    dps[ch][3] = t4.w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // hop 1, reader side: r of Gaussian `row` in plane row, w in plane 4 + row; four consecutive lanes = this reducer's pixels
+  const float4 *rd_r = reinterpret_cast<const float4 *>(&s_rw[row * WAVE + kcol * 4u]);
+  const float4 *rd_w = reinterpret_cast<const float4 *>(&s_rw[(4u + row) * WAVE + kcol * 4u]);
+  // second hop: which (half, value) column k < 9 of the gradient row this lane owns
+  //   column k: 0 r dx (lower qb) 1 r dy (upper qa) 2 r dx^2 (lower qc) 3 r dx dy (upper qb) 4 r dy^2 (upper qc)
+  //             5 r (lower qa)    6 red (lower ka)  7 green (upper ka)   8 blue (lower kb)
+  constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;  // bit k: upper half
+  constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;   // nibble k: which of qa..kb (0..4)
+  const uint32_t k9 = kcol < 9u ? kcol : 0u;
+  const uint32_t hk = (uint32_t)((HALF_OF_K >> k9) & 1u), vk = (uint32_t)((VAL_OF_K >> (4u * k9)) & 0xFu);
+  const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2u + hk) * 5u + vk) * 8u]);
+  float *t2 = &s_rw[((row * 2u + (upper ? 1u : 0u)) * 5u) * 8u + jj];
+
+  for (int base = skip; base < walk_end; base += WAVE) {
+    // ---- fetch 64 entries (from the back), cull, compact into LDS in back-to-front order
+    const int idx = base + (int)lane;
+    bool keep = false;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    float l255 = 0.f;
+    uint32_t id = 0;
+    if (idx < walk_end) {
+      id = a.point_list[range.y - 1 - idx];
+      const float4 *src = reinterpret_cast<const float4 *>(a.recs + id);
+      r0 = src[0];
+      r2 = src[2];
+      keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
+      if (keep) {  // second, exact filter: ellipse {alpha >= 1/255} against the wave's pixel rectangle
+        r1 = src[1];
+        l255 = __builtin_amdgcn_logf(255.0f * r1.y);
+        keep = ellipse_hits_rect_fast(r0.x, r0.y, r0.z, r0.w, r1.x, l255, rx0, rx1, ry0, ry1);
+      }
+    }
+    const uint64_t kmask = __ballot(keep);
+    const int cnt = __builtin_popcountll(kmask);
+    if (keep) {
+      const int slot = __builtin_popcountll(kmask & lt);
+      // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
+      constexpr float L2E = 1.4426950408889634f;
+      s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
+      s1[slot] = make_float4((-0.5f * L2E) * r1.x, l255, __uint_as_float((uint32_t)(n - 1 - idx)), r1.y);
+      s2[slot] = make_float4(r1.w, r2.x, r2.y, r1.z);
+      s_id[slot] = id * (uint32_t)(GROW * sizeof(float));  // (P < 2^25: gsr_rasterize_backward refuses more)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // byte offset of the group's first survivor row (and of this reducer row's id): wave-uniform in fact, kept in VGPRs (the asm
+    // hides that from the compiler, which would otherwise move the scalar address into a VGPR in front of every LDS read)
+    uint32_t vg = 0u, vi = row * 4u;
+    asm volatile("" : "+v"(vg), "+v"(vi));
+    for (int g = 0; g < cnt; g += 4, vg += 64u, vi += 16u) {
+      float ar[4], aw[4];  // (r, w) of this lane's pixel for the group's four Gaussians (0 where it is not hit)
+      uint32_t anyhit = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        bool done = false;
+        if (g + u < cnt) {  // wave-uniform
+          const float4 g0 = lds_at<float4>(s0, vg + 16u * u);
+          float4 g1 = lds_at<float4>(s1, vg + 16u * u);
+          keep_whole(g1);
+          const int fpos = (int)__float_as_uint(g1.z);  // 0-based position from the front
+          const float dx = g0.x - pxf, dy = g0.y - pyf;
+          const float p2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;  // power * log2(e)
+          const bool pre = (fpos < lastc) && !(p2 > 0.0f) && (p2 + g1.y >= -0.02f);
+          if (__ballot(pre) != 0ull) {  // wave-uniform: some lane may reach alpha >= 1/255
+            // select form: on lanes that are not hit alpha and G are forced to zero, which makes every update below an exact no-op
+            // (rc = 1, Tn = T, w = 0, r = 0)
+            float4 g2 = lds_at<float4>(s2, vg + 16u * u);
+            keep_whole(g2);
+            const float G0 = __builtin_amdgcn_exp2f(p2);
+            const float alpha0 = fminf(0.99f, g1.w * G0);
+            const bool hit = pre && !(alpha0 < 1.0f / 255.0f);
+            const float alpha = hit ? alpha0 : 0.f, G = hit ? G0 : 0.f;
+            const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+            const float Tn = T * rc;  // transmittance in front of this Gaussian
+            const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
+            float e = __builtin_fmaf(g2.x, dpix0, dalp);
+            e = __builtin_fmaf(g2.y, dpix1, e);
+            e = __builtin_fmaf(g2.z, dpix2, e);
+            if (DEPTH) e = __builtin_fmaf(g2.w, ddep, e);
+            const float dL_dalpha = Tn * e - XT * rc;
+            XT = __builtin_fmaf(w, e, XT);
+            T = Tn;
+            ar[u] = G * dL_dalpha;  // r = G dL_dalpha: its moments over the pixels become dL_dmean2D / dL_dconic in preprocess_bwd.hip
+            aw[u] = w;
+            anyhit |= 1u << u;
+            done = true;
+          }
+        }
+        if (!done) {  // (wave-uniform) skipped: its sums must read as zero in the reduction -- two moves on THIS path only
+          asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(ar[u]), "=v"(aw[u]));
+        }
+      }
+      if (anyhit) {  // wave-uniform
+        // the hit bits already say g + row < cnt (bit u is set inside that test)
+        const bool row_live = (anyhit & rowbit) != 0u;
+        const uint32_t goff = lds_at<uint32_t>(s_id, vi);   // (stale LDS beyond cnt: never used)
+        const float2 gxy = lds_at<float2>(s0, vg + row16);  // this row's Gaussian centre
+        // hop 1: eight lane-linear planes, ds_write_addtid_b32 (address = M0 + offset + 4 x lane)
+        asm volatile(
+            "s_mov_b32 m0, %8\n\t"
+            "s_nop 0\n\t"  // (an M0 write needs one wait state before an add-TID LDS instruction reads it)
+            "ds_write_addtid_b32 %0 offset:0\n\t"
+            "ds_write_addtid_b32 %1 offset:256\n\t"
+            "ds_write_addtid_b32 %2 offset:512\n\t"
+            "ds_write_addtid_b32 %3 offset:768\n\t"
+            "ds_write_addtid_b32 %4 offset:1024\n\t"
+            "ds_write_addtid_b32 %5 offset:1280\n\t"
+            "ds_write_addtid_b32 %6 offset:1536\n\t"
+            "ds_write_addtid_b32 %7 offset:1792"
+            :
+            : "v"(ar[0]), "v"(ar[1]), "v"(ar[2]), "v"(ar[3]), "v"(aw[0]), "v"(aw[1]), "v"(aw[2]), "v"(aw[3]), "s"(rw_base)
+            : "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 r4 = *rd_r, w4 = *rd_w;
+        __builtin_amdgcn_wave_barrier();  // the second hop's stores stay behind these reads
+        // this lane's four pixels: column kcol & 7, rows ly = 2 q + h, h = kcol >> 3
+        const float dxr = gxy.x - colx;                       // against this lane's column
+        const float e0 = (r4.x + r4.y) + (r4.z + r4.w);
+        const float A1 = r4.y + 2.f * r4.z + 3.f * r4.w;      // sum q r
+        const float A2 = r4.y + 4.f * r4.z + 9.f * r4.w;      // sum q^2 r
+        const float sy1 = 2.f * A1 + hh * e0;                 // sum ly r
+        const float sy2 = 4.f * A2 + hh * (4.f * A1 + e0);    // sum ly^2 r   (h^2 = h)
+        const float Dy = gxy.y - qtop;                        // mean.y - top pixel row of the quadrant
+        float c[6];
+        c[0] = e0;
+        c[1] = Dy * e0 - sy1;                        // partial column sum of r dy
+        c[2] = Dy * (Dy * e0 - 2.f * sy1) + sy2;     // partial column sum of r dy^2
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) c[3 + ch] = (w4.x * dps[ch][0] + w4.y * dps[ch][1]) + (w4.z * dps[ch][2] + w4.w * dps[ch][3]);
+        const float qa = pack_halves(c[0], c[1], upper);
+        const float qb = qa * dxr;
+        const float c2 = c[2] + dpp_f<0x128>(c[2]);
+        const float qc = upper ? c2 : qb * dxr;
+        const float ka = pack_halves(c[3], c[4], upper);
+        const float kb = c[5] + dpp_f<0x128>(c[5]);
+        // second hop: lane (row, half, jx) leaves its five half-row values as [row][half][value][jx]; lane (row, column k < 9) reads
+        // the eight jx of ITS (half, value) -- two 16-byte loads -- adds them and owns column k of the Gaussian's gradient row
+        t2[0] = qa;
+        t2[8] = qb;
+        t2[16] = qc;
+        t2[24] = ka;
+        t2[32] = kb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 lo4 = src8[0], hi4 = src8[1];
+        __builtin_amdgcn_wave_barrier();  // the next group's hop-1 stores stay behind these reads
+        const float vsum = ((lo4.x + lo4.y) + (lo4.z + lo4.w)) + ((hi4.x + hi4.y) + (hi4.z + hi4.w));
+        // (a.debug_skip_atomics: measurement only -- what the kernel costs WITHOUT its gradient-row atomics)
+        if (row_live && kcol < (uint32_t)NACC && !a.debug_skip_atomics)
+          atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(a.grad_rows) + (size_t)(goff + kcol * 4u)), vsum);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // keep the next batch's LDS writes behind this batch's reads
+  }
+  if (a.trace && lane == 0) {
+    unsigned long long *r = a.trace + (size_t)blockIdx.x * 4u;
+    r[0] = trace_t0;
+    r[1] = __builtin_amdgcn_s_memrealtime();
+    r[2] = (unsigned long long)(walk_end - skip > 0 ? walk_end - skip : 0) | ((unsigned long long)n << 32);
+    r[3] = (unsigned long long)tile | ((unsigned long long)seg << 32);
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // RED = 2: the per-Gaussian sums over the 64 pixels of a quadrant as a matrix product on the (otherwise idle) matrix pipe.
@@ -1247,7 +1554,12 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     hipLaunchKernelGGL((blend_backward_kernel<1, 0, CE_MAX>), dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
-  if (opt.blend_bwd_reduce == 3 && opt.blend_bwd_waves == 4) {
+  if (opt.blend_bwd_reduce == 3 && opt.blend_bwd_waves == 4) {  // the default
+    if (a.loss_gt) hipLaunchKernelGGL(blend_backward_lds_kernel<false>, dim3(slots * 4), dim3(WAVE), 0, stream, a);  // (no depth term)
+    else hipLaunchKernelGGL(blend_backward_lds_kernel<true>, dim3(slots * 4), dim3(WAVE), 0, stream, a);
+    return GSR_OK;
+  }
+  if (opt.blend_bwd_reduce == 4 && opt.blend_bwd_waves == 4) {  // round 3's instantiation of the same design, kept for A/B this round
     hipLaunchKernelGGL((blend_backward_kernel<1, 3, 0>), dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }

@@ -119,7 +119,7 @@ static int set_option(Options &o, const char *key, int v) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.tile_cull = v;
   } else if (!strcmp(key, "blend_bwd_reduce")) {
-    if (v < 0 || v > 3) return bad("0 (permlane / DPP folds), 1 (MFMA on folded rows), 2 (transposed MFMA contraction) or 3 (LDS folds)");
+    if (v < 0 || v > 4) return bad("0 (permlane / DPP folds), 1 (MFMA on folded rows), 2 (transposed MFMA contraction), 3 (LDS folds) or 4 (LDS folds, the round-3 kernel)");
     o.blend_bwd_reduce = v;
   } else if (!strcmp(key, "blend_layout")) {
     if (v != 0 && v != 1) return bad("0 (quadrant waves) or 1 (4x4 blocks, four survivors per step)");
@@ -643,6 +643,10 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
     return GSR_EINVAL;
   }
   if (P == 0) return GSR_OK;
+  if (P >= (1 << 25)) {  // the blend backward keeps a Gaussian's gradient row as a 32-bit byte offset (rows of up to 128 bytes)
+    set_error("gsr_rasterize_backward: at most 2^25 - 1 Gaussians per call");
+    return GSR_EINVAL;
+  }
   if (!geom_buffer || !binning_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !campos ||
       !dL_dpix || !dL_ddepths || !dL_dalphas || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
       !dL_dcov3D) {

@@ -459,6 +459,32 @@ __device__ __forceinline__ bool ellipse_hits_rect(float gx, float gy, float A, f
   return qmin <= thr;
 }
 
+// The same test for the blend kernels' per-wave compaction, where it is pure work saving (an entry kept in error costs a cut-off
+// test, nothing else, and the 1.0001 / 0.05 margins of the threshold cover a rounding in 1/A, 1/C): hardware reciprocals instead of
+// two IEEE divisions (2 instead of ~22 VALU instructions per batch of 64 list entries) and log2(255 o) handed in by the caller, who
+// needs it for the survivor's LDS row anyway.  The binning's tile culling keeps ellipse_hits_rect: its decisions define the lists.
+__device__ __forceinline__ bool ellipse_hits_rect_fast(float gx, float gy, float A, float B, float C, float log2_255o, float x0,
+                                                       float x1, float y0, float y1) {
+  if (!(A > 0.f && C > 0.f && A * C - B * B > 0.f)) return true;
+  const float thr = 2.0f * 0.6931471805599453f * log2_255o * 1.0001f + 0.05f;
+  const float dxl = gx - x1, dxh = gx - x0, dyl = gy - y1, dyh = gy - y0;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;  // centre inside
+  float qmin = 3.0e38f;
+  const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const float dx = e ? dxh : dxl;
+    const float dy = fminf(dyh, fmaxf(dyl, -B * dx * rC));
+    qmin = fminf(qmin, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+    const float ey = e ? dyh : dyl;
+    const float ex = fminf(dxh, fmaxf(dxl, -B * ey * rA));
+    qmin = fminf(qmin, A * ex * ex + 2.0f * B * ex * ey + C * ey * ey);
+  }
+  // (a clamped minimiser that is off by an ulp of 1/A still lies ON the edge: q there is >= the edge's true minimum, and the margins
+  // of thr are orders of magnitude above that difference)
+  return qmin <= thr * 1.00001f + 1e-3f;
+}
+
 // Zero-fill as a KERNEL, not as a hipMemsetAsync: under the HIP runtime's graph packet capture (ROCm 7.2 default) a memset NODE
 // on memory of a hipGraph's private pool replays wrong once other GPU work has run between two replays
 // (tools/graph_bisect.py, profiles/r3_graph_bisect.txt: a bare hipMemsetAsync + one torch add, no libgsr involved, is off by
