@@ -37,9 +37,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); measured copy ceiling is ~6300
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
-# ns per wave64 v_fma_f32 per SIMD with 8 waves per SIMD, measured on MI355X (tools/ubench/valu_rate.hip,
-# profiles/r2_ubench_valu_rate.txt): the cheapest VALU instruction; v_pk_fma_f32 costs twice that (no gain per float)
-VALU_FMA_NS = 1.08
+# cycles per wave64 VALU instruction per SIMD: a SIMD-32 issues the 64 lanes of a v_fma_f32 in two cycles
+# (MI355X_MICROARCH.md "Wave scheduling"); the issue floor of a kernel is instructions x 2 cycles / 1024 SIMDs at the shader
+# clock MEASURED on this box in this run (gsr_debug_clock_probe) -- rounds 1-3 priced it with a constant 1.08 ns taken on a cold GPU
+VALU_CYCLES = 2.0
 
 WORKLOADS = {
     "C2": dict(P=50_000, W=512, H=512, deg=0, backward=False, desc="50k Gaussians, SH0, 512x512, forward only"),
@@ -538,24 +539,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- untimed: warm-up, then a pass with every stage bracketed by events to find the dominant kernel
+    # ---- untimed: a pass with every stage bracketed by events to find the dominant kernel (before the warm-up: the stage events
+    # synchronise, and nothing may sit between the warm-up and the timed region)
+    sc.one_step()
+    stage_ms_cold = None
+    for _ in range(2):  # (two passes, the smaller average per stage: one stray preemption must not pick the kernel)
+        _lib.profile_enable(_lib.PROF_STAGES)
+        for _ in range(4):
+            sc.one_step()
+        torch.cuda.synchronize()
+        cur = {k: (ms / n if n else 0.0) for k, (ms, n) in _lib.profile_read().items()}
+        stage_ms_cold = cur if stage_ms_cold is None else {k: min(v, stage_ms_cold[k]) for k, v in cur.items()}
+    dominant = max(stage_ms_cold, key=stage_ms_cold.get)
+    _lib.profile_enable([dominant])  # only the dominant kernel keeps its two event records in the timed region
+    # ---- untimed: bring the GPU to the shader clock it sustains.  A freshly leased MI355X starts at 2.26 GHz and needs ~20 ms of
+    # load to reach 2.39-2.40 (it falls back after 50 ms of idle: tools/clock_ramp.py, profiles/r4_clock_ramp.txt); the driver's
+    # `--steps 20 --warmup 5` is 13 ms of work in all and read 10 % below a 300-step run of the same build on the same box (round 4).
+    # The probe (a dependent FMA chain per SIMD bracketed by s_memtime and the 100 MHz counter) runs until five readings agree,
+    # then the W warm-up steps and the K timed steps follow back to back; the clock is read again right after the timed region.
+    clock_hist = _lib.settle_clock(dev)
+    clock_before = clock_hist[-1][1]
     for _ in range(max(1, a.warmup)):
         sc.one_step()
-    sync()
-    _lib.profile_enable(_lib.PROF_STAGES)
-    for _ in range(5):
-        sc.one_step()
-    torch.cuda.synchronize()
-    prof = _lib.profile_read()
-    stage_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in prof.items()}
-    dominant = max(stage_ms, key=stage_ms.get)
-    _lib.profile_enable([dominant])  # only the dominant kernel keeps its two event records in the timed region
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     if sc.step is not None:
         sc.step.timer.reset()
     elapsed, per_step = timed(sc.one_step, a.steps, sync)
+    clock_after = _lib.clock_probe(1024, 1 << 19, dev)[0]
     ex_ms = sc.step.timer.read_ms() if sc.step is not None else []
+    # stage times at the settled clock (the pass above ran on a cold GPU and only chose the kernel to time)
+    dom_ms, dom_n = _lib.profile_read()[dominant]
+    _lib.profile_enable(_lib.PROF_STAGES)
+    for _ in range(5):
+        sc.one_step()
+    torch.cuda.synchronize()
+    stage_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in _lib.profile_read().items()}
+    _lib.profile_enable([])
     ls = sc.list_stats()  # (synchronises; after the timed region)
     t = torch.tensor([elapsed, float(np.mean(ex_ms)) if ex_ms else 0.0], dtype=torch.float64, device=dev)
     Rt = torch.tensor([float(ls["instances_after_tile_cull"])], dtype=torch.float64, device=dev)
@@ -564,8 +584,6 @@ def main():
         parallel.all_reduce_(Rt, dist.ReduceOp.SUM)
     elapsed, exchange_ms = float(t[0]), float(t[1])
     sc.check()
-    dom_ms, dom_n = _lib.profile_read()[dominant]
-    _lib.profile_enable([])
 
     out = None
     if rank == 0:
@@ -583,26 +601,21 @@ def main():
                 "algorithmic_bytes_per_launch": int(sb[dominant]), "algorithmic_bytes_per_launch_reference_R": int(sb_ref[dominant]),
                 "avg_launch_ms": round(dom_avg_ms, 5), "launches_timed": int(dom_n)}
         if pmc:
-            roof["traffic_source"] = pmc["source"] + " (2 x FETCH_SIZE + WRITE_SIZE per launch; WRITE_SIZE counts every float-atomic lane as 4 B)"
+            roof["traffic_source"] = pmc["source"] + (" (counters collected on the builder's box, not in this run: 2 x FETCH_SIZE + WRITE_SIZE "
+                                                      "per launch; WRITE_SIZE counts every float-atomic lane as 4 B)")
         if pmc and "valu_insts" in pmc and dom_avg_ms > 0:
-            # The blend kernels are bound by vector-instruction ISSUE, not by HBM.  Issue roofline of the kernel as it is:
-            # every wave64 VALU instruction holds its SIMD for at least the time of an FMA (VALU_FMA_NS, measured); a kernel made
-            # of the same number of instructions cannot run faster than  insts x VALU_FMA_NS / 1024 SIMDs.  frac = that floor /
-            # the measured launch time; ns_per_inst = what an instruction really costs here (exp / rcp 3.3x, DPP and permlane
-            # swaps 4x, compare+select 1.7x an FMA: profiles/r2_ubench_valu_rate.txt).
+            # Issue roofline of the kernel as it is: a SIMD issues a wave64 VALU instruction in VALU_CYCLES cycles at best, so a kernel
+            # made of the same number of instructions cannot run faster than  insts x VALU_CYCLES / 1024 SIMDs / clock  -- priced at
+            # the shader clock MEASURED in this run.  frac = that floor / the measured launch time.  (Rounds 1-3 read frac ~ 0.6
+            # plus a counter-derived "busy" of ~1.0 as "issue-bound"; round 4's census says the LDS array is the busier unit.)
             n_i = pmc["valu_insts"]
-            floor_ms = n_i * VALU_FMA_NS / N_SIMD * 1e-6
+            floor_ms = n_i * VALU_CYCLES / N_SIMD / (clock_before * 1e9) * 1e3
             roof["valu_issue"] = {
-                "bound": "valu_issue", "valu_insts_per_launch": int(n_i), "fma_ns_per_inst_per_simd": VALU_FMA_NS,
-                "floor_ms_if_all_fma": round(floor_ms, 5), "frac": round(floor_ms / dom_avg_ms, 4),
-                "ns_per_inst_per_simd": round(dom_avg_ms * 1e6 * N_SIMD / n_i, 3),
-                "insts_per_walked_instance": round(n_i / max(R_walked, 1), 1), "source": pmc["source"]}
-            if "active_inst_valu_quads" in pmc and pmc.get("avg_us_under_pmc"):
-                # busy fraction straight from the counters, unclamped: SQ_ACTIVE_INST_VALU (quad-cycles summed over all SIMDs) x 4
-                # over 1024 SIMDs x the kernel's cycles at the clock implied by SQ_BUSY_CYCLES (summed over 32 shader engines)
-                cyc = pmc["sq_busy_cycles"] / 32.0
-                roof["valu_issue"]["valu_busy_frac_pmc"] = round(4.0 * pmc["active_inst_valu_quads"] / (cyc * N_SIMD), 3)
-                roof["valu_issue"]["clock_ghz_pmc"] = round(cyc / (pmc["avg_us_under_pmc"] * 1e3), 3)
+                "bound": "valu_issue", "valu_insts_per_launch": int(n_i), "cycles_per_inst_per_simd_floor": VALU_CYCLES,
+                "clock_ghz": clock_before, "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / dom_avg_ms, 4),
+                "cycles_per_inst_per_simd": round(dom_avg_ms * 1e-3 * clock_before * 1e9 * N_SIMD / n_i, 3),
+                "insts_per_walked_instance": round(n_i / max(R_walked, 1), 1),
+                "source": pmc["source"] + " (instruction count: the builder's box; launch time and clock: this run)"}
         out = {
             "metric": "frames/sec fwd+bwd @1024^2, 200k Gaussians" if a.workload == "C3" else f"frames/sec {wl['desc']}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -623,6 +636,10 @@ def main():
                        "binning": "tile_bucket" if _lib.lib.gsr_get_binning_mode() == 1 else "global_radix",
                        "host_sync_per_step": 0, "backend": (dist.get_backend() if world > 1 else None)},
             "step_ms": pct(per_step),
+            # shader clock (s_memtime over the 100 MHz counter, gsr_debug_clock_probe) when the settle loop ended, i.e. right before
+            # the warm-up steps, and right after the timed region; first = the clock the process found the GPU at
+            "device_clock_ghz_measured": round(clock_before, 4), "device_clock_ghz_after": round(clock_after, 4),
+            "device_clock_ghz_first": clock_hist[0][1], "clock_settle_ms": clock_hist[-1][0],
             # N > 1: HIP events around the collectives of every step (max over ranks of the per-rank mean) and what is left of the
             # step -- so that a scaling run says where its time went
             "exchange_ms": round(exchange_ms, 4) if world > 1 else None,

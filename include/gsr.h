@@ -101,10 +101,10 @@ int gsr_profile_enable(unsigned stage_mask);
  * + 64) always suffices; a rasterizer call that finds the buffer too small fails with GSR_EINVAL); NULL switches it off. */
 int gsr_debug_wave_trace(unsigned long long *device_buffer, size_t words);
 /* Measurement only: the shader clock the device runs at right now.  `workgroups` (1 .. 2048) single-wave workgroups each run a
- * dependent chain of `fmas` v_fma_f32 (four cycles each for a wave that shares its SIMD with at most one other) bracketed by the
- * constant 100 MHz counter; device_out[2 i] = 10 ns ticks, device_out[2 i + 1] = s_memtime ticks of workgroup i.
- * clock = 4 fmas / (ticks x 10 ns).  bench.py prints it next to every figure that scales with the clock (the blend kernels are
- * bound by vector-instruction issue) and runs it until the clock has settled before its warm-up steps. */
+ * dependent chain of `fmas` v_fma_f32 bracketed by the constant 100 MHz counter and by s_memtime (which ticks with the shader
+ * clock on gfx950): device_out[2 i] = 10 ns ticks, device_out[2 i + 1] = shader cycles of workgroup i;
+ * clock = cycles / (ticks x 10 ns).  bench.py prints it next to every figure that scales with the clock and runs the probe until
+ * the clock has settled before its warm-up steps (a freshly leased MI355X needs ~20 ms of load to go from 2.26 to 2.39 GHz). */
 int gsr_debug_clock_probe(int workgroups, int fmas, unsigned long long *device_out, gsr_stream_t stream);
 int gsr_profile_reset(void);
 int gsr_profile_read(int stage, double *total_ms, long *launches);

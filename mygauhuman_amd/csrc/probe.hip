@@ -6,11 +6,11 @@
 // VALU-bound stage slower by the same factor, the HBM-bound ones unchanged).  A bench line therefore has to say at what clock it
 // was taken, and a short run has to get the chip to its sustained clock before its warm-up steps.
 //
-// One wave per workgroup runs a dependent chain of `fmas` v_fma_f32: a wave alone on its SIMD issues one every FOUR cycles
-// (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), and two waves that share a SIMD still get a slot every four cycles
-// each, so with <= 2048 workgroups on the chip  cycles = 4 x fmas  whatever the placement.  The constant 100 MHz counter
-// (s_memrealtime) brackets the chain:  clock = 4 x fmas / (ticks x 10 ns).  s_memtime is recorded beside it: on parts where it
-// counts shader cycles the two clocks must agree (the Python side prints both).
+// One wave per workgroup runs a dependent chain of `fmas` v_fma_f32 (something for the SIMDs to do: the clock is a function of
+// load) bracketed by two counters: s_memrealtime (constant 100 MHz) and s_memtime, which on gfx950 ticks with the shader clock
+// (measured: 2.26 ticks per ns on a cold device, 2.39-2.40 after 20 ms of load; tools/clock_ramp.py).
+//   clock = s_memtime ticks / (100 MHz ticks x 10 ns).
+// The chain itself runs at 8.8 cycles per dependent FMA whatever the clock: reported as a sanity value.
 #include "gsr_common.h"
 
 namespace gsr {
