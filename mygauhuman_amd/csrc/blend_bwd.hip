@@ -1162,7 +1162,9 @@ constexpr int FB = 32;                 // survivors staged at a time
 constexpr int FX_LROW = 10;            // floats per pixel lane in the transposition buffer: 4 x (r, w) + 2 pad (12 as in LFOLD above would
                                        // cost 256 bytes that decide between six and seven LDS granules per wave, see s_rw)
 constexpr int FX_BASE2 = 4 * 2 * 5 * 8;  // floats of the base sums' second hop
-constexpr int FX_TRI2 = 4 * 3 * 16;      // floats of one colour triple's second hop (two triples per pass)
+constexpr int FX_TRI2 = 4 * 3 * 16 + 4;  // floats of one colour triple's second hop (two triples per pass); + 4 (round 4): the second
+                                         // triple's 16-float rows start four banks after the first's -- the readers of both (lanes k < 3
+                                         // and 3 <= k < 6 of a row, one 16-byte read each) hit the same banks otherwise (2-way conflict)
 #ifndef FX_FULL_ROWS
 #define FX_FULL_ROWS false
 #endif
