@@ -273,7 +273,8 @@ def extra_workload(name, dev, steps=60, warmup=5):
 
 
 RENDER_WL = dict(P=200_000, V=6890, W=1024, H=1024, desc="render(): 200k articulated Gaussians (LBS -> attributes -> fused 21-channel "
-                 "raster), 1024x1024, fwd+bwd, phase-1 loss (image, alpha, normal, axis)")
+                 "raster), 1024x1024, fwd+bwd, phase-1 loss (image, alpha, normal, axis); motion decoders off in the 1-GPU `extra` "
+                 "figure, stand-ins in --workload render")
 PHASE1_KEYS = ("render", "render_alpha", "normal", "render_axis")   # the images train.py:256-286 puts in the loss before the PBR phase
 
 
@@ -474,6 +475,9 @@ def main_render(a, rank, world, local, dev, rehearsal):
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": wl["desc"] + f"; S-human seed 0, {world} ring view(s)/step, 1 view/rank, own pose per view; "
+                          "motion decoders = STAND-INS (a 69-128-69 pose MLP and an affine 96-parameter skinning-offset map), NOT the "
+                          "reference's nets/mlp_delta_*.py -- its per-Gaussian offset MLP (63-d embedding, 4 x 128 Conv1d, run every "
+                          "frame: gaussian_renderer/__init__.py:100-106) is outside the scoped path and its cost is NOT in this figure; "
                           + ("REHEARSAL: all ranks on ONE device over gloo with host-staged collectives -- not a scaling number; "
                              if rehearsal else "") + f"exchange payload {step.payload_bytes / 1e6:.1f} MB/rank"
                           + (" (compact SH: all-gather + all-reduce)" if step.compact is not None else " (one all-reduce)"),

@@ -48,7 +48,11 @@ class GraphedFrame:
         backward allocates them from the graph's pool (they stay valid between replays).
         verify: replay twice with unrelated eager GPU work in between and compare the gradients (and the tensors step_fn returns)
         with the eager warm-up step to verify_rtol of each tensor's largest magnitude (float atomics reorder sums; the failure
-        this guards against is off by many orders of magnitude); raises RuntimeError on a mismatch."""
+        this guards against is off by many orders of magnitude); raises RuntimeError on a mismatch.
+        verify=True REQUIRES a deterministic step_fn without side effects: the constructor runs it `warmup` + 1 times and replays
+        it twice, so per-call randomness (the reference's random_background) fails the comparison spuriously and anything the step
+        accumulates in place (statistics, an optimizer step inside it) is applied that many extra times.  Such a step is captured
+        with verify=False, which in turn demands DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment."""
         # Without the self-check there is nothing to stand on unless the runtime's graph packet capture is known to be off
         if not verify and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
             raise RuntimeError("GraphedFrame(verify=False): DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before the HIP "
@@ -104,14 +108,19 @@ class GraphedFrame:
             for k, (got, want) in enumerate(zip(live, eager_ref)):
                 if got is None or want is None or got.shape != want.shape:
                     continue
+                if want.numel() == 0:
+                    continue
                 scale = float(want.detach().abs().max())
                 err = float((got.detach().float() - want.float()).abs().max())
                 if not (err <= rtol * scale + 1e-30) or not bool(torch.isfinite(got.detach()).all()):
                     raise RuntimeError(
                         f"GraphedFrame self-check failed ({tag}, tensor {k}: max error {err:.3e} against a magnitude of {scale:.3e}): "
-                        "the replayed graph does not reproduce the eager step.  On ROCm 7.2 this is what the HIP runtime's graph "
-                        "packet capture does to memset nodes on graph-pool memory -- DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the "
-                        "environment BEFORE the first HIP call of the process (torch.cuda.is_available() counts).")
+                        "the replay differs from the eager step.  Possible causes: (a) step_fn is not deterministic or has side "
+                        "effects -- per-call randomness such as a random background, parameters or statistics updated in place "
+                        "inside the step (verify=True replays the step twice more than you asked for: pass verify=False for such "
+                        "a step); (b) on ROCm 7.2, the HIP runtime's graph packet capture replays memset nodes on graph-pool "
+                        "memory wrongly -- DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment BEFORE the first HIP call "
+                        "of the process (torch.cuda.is_available() counts).")
         self.replay()
         compare("first replay")
         dev = live[0].device if live else torch.device("cuda")

@@ -37,11 +37,16 @@ class PoseRefiner(torch.nn.Module):
 
 
 class LbsOffsetDecoder(torch.nn.Module):
-    """xyz [1,P,3] -> skinning-weight logit offsets [1,24,P] (LBSOffsetDecoder's call surface).  An AFFINE map of the position --
-    offsets[j] = b[j] + A[:, j] . xyz, 96 parameters, three broadcast multiply-adds -- not an MLP: the reference's network (a
-    63-d positional embedding through four 128-wide layers on every Gaussian, nets/mlp_delta_weight_lbs.py) is outside this hot
-    path, and a stand-in MLP with a 3- or 24-wide side spends the frame in rocBLAS' skinny-GEMM kernels (measured: a 3-64-24 MLP
-    on 200k points = 1.2 ms of two rocBLAS launches per frame, more than the whole render() frame)."""
+    """xyz [1,P,3] -> skinning-weight logit offsets [1,24,P] (LBSOffsetDecoder's call surface).  A STAND-IN, not the reference's
+    network: an AFFINE map of the position -- offsets[j] = b[j] + A[:, j] . xyz, 96 parameters, three broadcast multiply-adds.
+    The reference runs its real decoder EVERY frame when motion_offset_flag is set (gaussian_renderer/__init__.py:100-106 calls
+    pc.lweight_offset_decoder(means3D)): a 63-d positional embedding through four 128-wide Conv1d layers on every Gaussian
+    (nets/mlp_delta_weight_lbs.py), i.e. ~2 x (63 x 128 + 3 x 128 x 128 + 128 x 24) = 120 kFLOP per Gaussian per frame forward,
+    a 200k x 128 GEMM chain that is likely the largest single cost of the reference's own step.  That network is outside SURVEY.md
+    section 8 (render() calls whatever `pc.lweight_offset_decoder` is), so every figure measured with this stand-in -- `bench.py
+    --workload render`, the view-parallel payload -- OMITS it, and the bench line says so in config.workload.  (A stand-in MLP with
+    a 3- or 24-wide side spends the frame in rocBLAS' skinny-GEMM kernels: a 3-64-24 MLP on 200k points measured 1.2 ms of two
+    rocBLAS launches per frame, more than the whole render() frame -- which is why the stand-in is affine.)"""
 
     def __init__(self, seed=1):
         super().__init__()

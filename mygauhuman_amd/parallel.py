@@ -140,27 +140,48 @@ def collective_selftest(device, group=None):
     recv = torch.zeros((world * 64,), dtype=torch.float32, device=device)
     want = torch.arange(1, world + 1, dtype=torch.float32, device=device).repeat_interleave(64)
     staged = _staged(send, group)
-    try:
-        if staged:
-            raise RuntimeError("host-staged rehearsal: list form")
-        dist.all_gather_into_tensor(recv, send, group=group)
-        if not torch.equal(recv, want):
-            raise RuntimeError("all_gather_into_tensor returned wrong data")
-    except Exception as ex:  # noqa: BLE001
+
+    def agree(ok):
+        """MIN over the ranks of a success flag, through host memory (gloo-style staging works on every backend and does not
+        depend on the collective under test): every rank takes the same branch below, so no rank posts a collective its peers
+        never post."""
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32)
+        objs = [None] * world
+        dist.all_gather_object(objs, float(flag[0]), group=group)
+        return min(objs) >= 1.0
+
+    err = None
+    if staged:
+        ok_here = False   # host-staged rehearsal: list form by construction (the same on every rank)
+    else:
+        try:
+            dist.all_gather_into_tensor(recv, send, group=group)
+            torch.cuda.synchronize(device) if torch.device(device).type == "cuda" else None  # (asynchronous RCCL errors surface here)
+            ok_here = bool(torch.equal(recv, want))
+            if not ok_here:
+                err = "all_gather_into_tensor returned wrong data"
+        except RuntimeError as ex:   # (a refused collective; anything else is a bug and propagates)
+            ok_here, err = False, str(ex)
+    if staged or not agree(ok_here):
         form = "list"
         if key not in _SELFTEST_DONE and not staged and rank == 0:
-            print(f"[mygauhuman_amd.parallel] all_gather_into_tensor unusable on backend {dist.get_backend(group)} ({ex}); "
-                  "falling back to the list form", flush=True)
+            print(f"[mygauhuman_amd.parallel] all_gather_into_tensor unusable on backend {dist.get_backend(group)} on at least one "
+                  f"rank ({err or 'a peer reported it'}); every rank falls back to the list form", flush=True)
         h = send.cpu() if staged else send
         parts = [torch.empty_like(h) for _ in range(world)]
-        dist.all_gather(parts, h, group=group)
-        got = torch.cat(parts).to(device)
-        if not torch.equal(got, want):
-            raise RuntimeError(f"all_gather self-test failed on backend {dist.get_backend(group)}")
+        ok_list, got = True, None
+        try:
+            dist.all_gather(parts, h, group=group)
+            got = torch.cat(parts).to(device)
+            ok_list = bool(torch.equal(got, want))
+        except RuntimeError:
+            ok_list = False
+        if not agree(ok_list):   # every rank raises, none is left waiting in a collective
+            raise RuntimeError(f"all_gather self-test failed on backend {dist.get_backend(group)} (tensor and list form) on at least one rank")
     red = send.clone()
     all_reduce_(red, dist.ReduceOp.SUM, group)
-    if not torch.equal(red, torch.full_like(red, world * (world + 1) / 2.0)):
-        raise RuntimeError(f"all_reduce self-test failed on backend {dist.get_backend(group)}")
+    if not agree(bool(torch.equal(red, torch.full_like(red, world * (world + 1) / 2.0)))):
+        raise RuntimeError(f"all_reduce self-test failed on backend {dist.get_backend(group)} on at least one rank")
     _SELFTEST_DONE.add(key)
     return form
 
@@ -537,6 +558,38 @@ class ViewParallelRender:
     def check(self):
         self._examine(block_older_than=self.steps)
 
+    def _current_leaves(self):
+        cur = OrderedDict()
+        for n in self.MODEL_LEAVES:
+            t = getattr(self.model, n, None)
+            if isinstance(t, torch.Tensor) and t.numel() and t.requires_grad:
+                cur[n] = t
+        for mod_name in ("pose_decoder", "lweight_offset_decoder"):
+            mod = getattr(self.model, mod_name, None)
+            if isinstance(mod, torch.nn.Module):
+                for n, p_ in mod.named_parameters():
+                    if p_.requires_grad:
+                        cur[f"{mod_name}.{n}"] = p_
+        return cur
+
+    def _rebind_leaves(self):
+        """The model may REPLACE a leaf between two steps without changing its shape -- densify.reset_opacity (train.py:412) installs
+        a new nn.Parameter for `_opacity`, optimizer surgery does the same for every group -- and render() then backpropagates into
+        the new tensor.  A step object that kept the old one would zero, reduce and hand back the gradient of a dead tensor while
+        the live one accumulated its own un-reduced gradient: replicas diverge silently.  So every call compares the
+        model's leaves with the ones this object is bound to: same names and shapes -> the new tensors are adopted (the bucket is
+        sized by shapes, nothing else changes); anything else -- densify / prune changed P, a leaf appeared or vanished -- raises and
+        asks for a new ViewParallelRender, whose bucket is sized for the new model."""
+        cur = self._current_leaves()
+        if int(self.model.get_xyz.shape[0]) != self.P or list(cur) != list(self.leaves) or any(
+                tuple(cur[n].shape) != tuple(self.leaves[n].shape) for n in cur):
+            raise RuntimeError(
+                "ViewParallelRender: the model's leaves changed (Gaussian count %d -> %d, or a leaf appeared / vanished / changed "
+                "shape): build a new ViewParallelRender after densify / prune" % (self.P, int(self.model.get_xyz.shape[0])))
+        for n, t in cur.items():
+            if t is not self.leaves[n]:
+                self.leaves[n] = t
+
     def __call__(self, iteration, camera, loss_fn, reduce=True, **render_kw):
         """loss_fn(out) -> scalar loss of this rank's view.  Returns (out, loss); afterwards p.grad of every leaf holds the mean
         over the ranks (reduce=True) and the statistics of the step are in .stat_grad_norm / .stat_visible / .max_radii."""
@@ -544,6 +597,7 @@ class ViewParallelRender:
         from .diff_gaussian_rasterization import _C as _RasterC
         from .gaussian_renderer import render
         self._examine(block_older_than=self.steps - self.max_in_flight)
+        self._rebind_leaves()
         dev, b = self.device, self.bucket
         for t in self.leaves.values():
             t.grad = None

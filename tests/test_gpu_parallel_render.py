@@ -121,6 +121,51 @@ def test_single_process_view_parallel_render_equals_plain_autograd():
         np.testing.assert_array_equal(step.max_radii.cpu().numpy(), rad)
 
 
+def test_a_replaced_leaf_is_followed_and_a_resized_model_is_refused():
+    """densify.reset_opacity (train.py:412) installs a NEW nn.Parameter of the same shape for `_opacity`: the step object must reduce
+    and hand back the gradient of the live tensor, not of the one it saw at construction; a model whose Gaussian count
+    changed must be refused with a message that says what to do."""
+    from mygauhuman_amd import human_synth, parallel
+    from tests.parallel_render_worker import image_weights, loss_of, pipe
+    model, body = human_synth.build(P, V, "cuda", seed=0, motion=True)
+    cam = human_synth.view_camera(body, W, H, 0, n_views=8, device="cuda")
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    weights = image_weights(W, H, 0, "cuda")
+    for compact in (True, False):
+        step = parallel.ViewParallelRender(model, pipe(), bg, compact_sh=compact)
+        step(1, cam, lambda o: loss_of(o, weights))
+        old = model._opacity
+        model._opacity = torch.nn.Parameter((old.detach() * 0.5 - 1.0).clone().requires_grad_(True))   # what reset_opacity does
+        step(2, cam, lambda o: loss_of(o, weights))
+        step.check()
+        assert step.leaves["_opacity"] is model._opacity
+        assert model._opacity.grad is not None and model._opacity.grad.data_ptr() == step.bucket["_opacity"].data_ptr()
+        # the same frame through plain render() + autograd
+        from mygauhuman_amd.gaussian_renderer import render
+        for p_ in step.leaves.values():
+            p_.grad = None
+        got = {n: None for n in step.leaves}
+        step(3, cam, lambda o: loss_of(o, weights))
+        got = {n: t.grad.detach().clone() for n, t in step.leaves.items()}
+        for p_ in step.leaves.values():
+            p_.grad = None
+        loss_of(render(3, cam, model, pipe(), bg), weights).backward()
+        for n, t in step.leaves.items():
+            if t.grad is None:
+                assert float(got[n].abs().max()) == 0.0, n
+                continue
+            util.assert_close(f"{n} after the leaf was replaced (compact={compact})", got[n].cpu().numpy(), t.grad.cpu().numpy(), tol=5e-5,
+                              max_bad_frac=1e-4, outer_tol=1e-3)
+        model._opacity = old
+    # a different Gaussian count: refused
+    step = parallel.ViewParallelRender(model, pipe(), bg, compact_sh=False)
+    keep = model._xyz
+    model._xyz = torch.nn.Parameter(keep.detach()[:-1].clone().requires_grad_(True))
+    with pytest.raises(RuntimeError, match="build a new ViewParallelRender"):
+        step(1, cam, lambda o: loss_of(o, weights))
+    model._xyz = keep
+
+
 def test_bench_render_workload_starts_its_own_ranks():
     """`python bench.py --workload render --gpus 2` (here: two ranks sharing the one GPU over gloo, a reduced Gaussian count):
     one JSON line with the exchange / compute split."""

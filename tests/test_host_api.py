@@ -105,6 +105,20 @@ def test_dropin_module_names():
     assert hasattr(diff_gaussian_rasterization._C, "mark_visible")
 
 
+def test_dropin_registers_the_renderer_for_train_py():
+    """train.py:17 does `from gaussian_renderer import render, network_gui`; train.py:180-193 only ever enters the viewer block when
+    network_gui.conn is not None."""
+    import mygauhuman_amd
+    mygauhuman_amd.install_dropin(render=True)
+    from gaussian_renderer import network_gui, render
+    import mygauhuman_amd.gaussian_renderer as ours
+    assert render is ours.render
+    assert network_gui.conn is None and network_gui.try_connect() is None
+    network_gui.init("127.0.0.1", 6009)
+    import inspect
+    assert list(inspect.signature(render).parameters)[:5] == ["iteration", "viewpoint_camera", "pc", "pipe", "bg_color"]
+
+
 def test_synthetic_scene_is_reproducible():
     from mygauhuman_amd import synthetic
     cam, g = synthetic.uniform_scene(1000, 64, 48, seed=0)
