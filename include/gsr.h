@@ -82,6 +82,12 @@ int gsr_get_binning_mode(void);
  *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above);
  *   "deterministic" in {0, 1}: the backward reduces its per-(Gaussian, tile-quadrant) partial sums in a fixed order instead of
  *       with float atomics: run-to-run bit-identical gradients (for tests; costs a 256-byte slot per instance quadrant).
+ *       PLAIN PASS ONLY, by design: the mode exists so that tests can demand bit equality where two code paths must produce the same
+ *       sums (the fused alpha-mask loss against loss kernel + backward; a knob against its default).  The fused 18-channel backward
+ *       (gsr_rasterize_backward_ex with extra features) returns GSR_EINVAL under it: a slot would be 27 columns wide (432 bytes per
+ *       instance quadrant, ~1 GB for a render() frame of 200k Gaussians), and what that pass has to be checked against -- seven
+ *       plain passes and the oracle, at 1e-4 -- differs from it in summation order anyway (tests/test_gpu_multi.py,
+ *       tests/test_gpu_render.py).
  * gsr_set_tuning sets the PROCESS DEFAULTS.  gsr_set_stream_tuning gives one stream its own set (initialised from the
  * defaults at its first call); every API call resolves its knobs once, at entry, from the stream it is given, so calls on
  * different streams are independent of each other whatever threads they come from (no mutable global state is consulted

@@ -1,5 +1,6 @@
 """GPU test of gaussian_renderer.render(): the whole articulated path (LBS deform -> covariance -> SH -> rasterizer)
 against the composition of the CPU oracle pieces, result-dict contract, and gradient flow to every parameter group."""
+import os
 import types
 
 import numpy as np
@@ -379,7 +380,8 @@ def test_render_features_and_parameter_gradients_match_oracle_composition(oracle
           feature passes) over the bit-identical per-Gaussian inputs, 1e-4 off the fragile pixels;
       (C) d(loss)/d(leaf) for _xyz, _features_dc, _features_rest, _scaling, _rotation, _opacity, _normal, _albedo (and the two
           decoder parameters) and the screen-space gradient vs  oracle.rasterize_backward (summed over the seven passes)
-          chained through float64 autograd of (A)."""
+          chained through float64 autograd of (A), at north_star's 1e-4 (rounds 2-3 held these to 3e-4 / 2e-4; measured in round 4:
+          they pass at 1e-4)."""
     from mygauhuman_amd import lbs
     from mygauhuman_amd.attributes import frame_attributes
     from mygauhuman_amd.gaussian_renderer import render
@@ -470,8 +472,8 @@ def test_render_features_and_parameter_gradients_match_oracle_composition(oracle
         g_mean, g_cov = g_mean + b["dL_dmeans3D"].astype(np.float64), g_cov + b["dL_dcov3D"].astype(np.float64)
         g_op, g_m2d = g_op + b["dL_dopacity"].astype(np.float64), g_m2d + b["dL_dmean2D"].astype(np.float64)
         g_sets.append(b["dL_dcolors"].astype(np.float64))
-    util.assert_close("viewspace_points.grad", out["viewspace_points"].grad.cpu().numpy(), g_m2d.reshape(P, 3), tol=2e-4,
-                      max_bad_frac=2e-4, outer_tol=2e-3)
+    util.assert_close("viewspace_points.grad", out["viewspace_points"].grad.cpu().numpy(), g_m2d.reshape(P, 3),
+                      tol=float(os.environ.get("GSR_RENDER_GRAD_TOL", 1e-4)), max_bad_frac=2e-4, outer_tol=2e-3)
     t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))  # noqa: E731
     outs = [ch["means3D"], ch["cov6"], ch["colors"], ch["features"], ch["opacity"]]
     gouts = [t64(g_mean), t64(g_cov), t64(g_sets[0]), t64(np.concatenate(g_sets[1:], axis=1)), t64(g_op.reshape(P, 1))]
@@ -480,7 +482,8 @@ def test_render_features_and_parameter_gradients_match_oracle_composition(oracle
     got = [p.grad for p in model.parameters()] + ([dec_mods[0].delta.grad, dec_mods[1].w.grad.reshape(24)] if motion else [])
     for n, g, wnt in zip(names + (("pose_decoder.delta", "lweight_offset_decoder.w") if motion else ()), got, want):
         assert g is not None and float(wnt.abs().max()) > 0, n
-        util.assert_close(f"d{n}", g.cpu().numpy().reshape(wnt.shape), wnt.numpy(), tol=3e-4, max_bad_frac=2e-4, outer_tol=3e-3)
+        util.assert_close(f"d{n}", g.cpu().numpy().reshape(wnt.shape), wnt.numpy(), tol=float(os.environ.get("GSR_RENDER_GRAD_TOL", 1e-4)),
+                          max_bad_frac=2e-4, outer_tol=3e-3)
 
 
 def test_forward_only_render_raises_on_the_overflowing_call(oracle, monkeypatch):
