@@ -273,9 +273,14 @@ def extra_workload(name, dev, steps=60, warmup=5):
 
 
 RENDER_WL = dict(P=200_000, V=6890, W=1024, H=1024, desc="render(): 200k articulated Gaussians (LBS -> attributes -> fused 21-channel "
-                 "raster), 1024x1024, fwd+bwd, phase-1 loss (image, alpha, normal, axis); motion decoders off in the 1-GPU `extra` "
-                 "figure, stand-ins in --workload render")
+                 "raster), 1024x1024, fwd+bwd, phase-1 training loss of train.py:261-265 (bound-masked L1 image / normal / axis + 0.1 L2 "
+                 "alpha); motion decoders off in the 1-GPU `extra` figure, stand-ins in --workload render")
 PHASE1_KEYS = ("render", "render_alpha", "normal", "render_axis")   # the images train.py:256-286 puts in the loss before the PBR phase
+
+
+def _phase1_loss(out):
+    """(tools/: the round-3 stand-in, four plain means)"""
+    return sum(out[k].mean() for k in PHASE1_KEYS)
 
 
 def _render_pipe():
@@ -283,78 +288,81 @@ def _render_pipe():
     return types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
 
 
-def _phase1_loss(out):
-    return sum(out[k].mean() for k in PHASE1_KEYS)
+def _phase1_targets(W, H, dev, seed=0):
+    """Synthetic targets of the phase-1 training loss (train.py:246-262): gt image, gt normal, background mask, bound mask (a box
+    around the subject with ragged edges, ~45 % of the pixels: what cv2.boundingRect-sized ZJU masks look like)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    gt_image = torch.from_numpy(rng.uniform(0, 1, (3, H, W)).astype(np.float32)).to(dev)
+    gt_normal = torch.from_numpy(rng.uniform(0, 1, (3, H, W)).astype(np.float32)).to(dev)
+    bkgd = torch.from_numpy((rng.uniform(0, 1, (1, H, W)) > 0.5).astype(np.float32)).to(dev)
+    bound = np.zeros((1, H, W), np.float32)
+    bound[:, H // 8: H - H // 8, W // 4: W - W // 4] = 1.0
+    return gt_image, gt_normal, bkgd, torch.from_numpy(bound).to(dev)
+
+
+def _phase1_loss_torch(out, gt_image, gt_normal, bkgd, bound):
+    """The loss of train.py:261-265 in torch ops, in the form a graph capture accepts (the reference's boolean-mask indexing has a
+    data-dependent shape: a host synchronisation per term; masked sums divided by the bound count are the same numbers)."""
+    nb = bound.sum()
+    l1 = lambda a, b: ((a - b).abs() * bound).sum() / (3.0 * nb)  # noqa: E731
+    mask_loss = (((out["render_alpha"] - bkgd) ** 2) * bound).sum() / nb
+    return l1(out["render"], gt_image) + 0.1 * mask_loss + l1(out["normal"], gt_normal) + l1(out["render_axis"], gt_normal)
 
 
 def render_extra(dev, steps=40, warmup=30):
     """render() forward + backward at 200k articulated Gaussians / 1024^2 through the drop-in signature
-    (gaussian_renderer/__init__.py:53), eager and as ONE hipGraph replay (mygauhuman_amd.graph.GraphedFrame) -- VERDICT r2 #5."""
+    (gaussian_renderer/__init__.py:53) with the phase-1 TRAINING loss of train.py:261-265 (bound-masked L1 on image / normal / axis,
+    0.1 L2 on alpha): fused with the rasterizer (render(..., fused_loss=Phase1Loss): the default figures `eager` / `one_graph`) and
+    written in torch ops (`torch_loss`), each eagerly and as ONE hipGraph replay (mygauhuman_amd.graph.GraphedFrame)."""
     import torch
 
     from mygauhuman_amd import human_synth
+    from mygauhuman_amd.diff_gaussian_rasterization._C import Phase1Loss
     from mygauhuman_amd.gaussian_renderer import render
     from mygauhuman_amd.graph import GraphedFrame
     wl = RENDER_WL
     model, body = human_synth.build(wl["P"], wl["V"], dev, seed=0)
     cam = human_synth.view_camera(body, wl["W"], wl["H"], 0, n_views=8, device=dev)
     bg, pipe, params = torch.zeros(3, device=dev), _render_pipe(), list(model.parameters())
+    targets = _phase1_targets(wl["W"], wl["H"], dev)
+    spec = Phase1Loss(*targets)
 
-    def step():
-        o = render(1, cam, model, pipe, bg)
-        _phase1_loss(o).backward()
+    def step_fused():
+        o = render(1, cam, model, pipe, bg, fused_loss=spec)
+        o["loss"].backward()
         return o["render"]
 
-    def eager():
-        for p in params:
-            p.grad = None
-        step()
-    for _ in range(warmup):
-        eager()
-    el, per = timed(eager, steps, torch.cuda.synchronize)
-    out = {"workload": wl["desc"], "eager": {"value": round(steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4),
-                                             "step_ms": pct(per)}}
-    try:
-        frame = GraphedFrame(step, warmup=3, zero_grads=params)   # verifies itself (replay / eager work / replay vs eager)
-        for _ in range(5):
-            frame.replay()
-        el, per = timed(frame.replay, steps, torch.cuda.synchronize)
-        frame.check()
-        out["one_graph"] = {"value": round(steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per),
-                            "self_check": "passed"}
-    except RuntimeError as ex:   # never silent: the line says why there is no graph number
-        out["one_graph"] = {"error": str(ex)[:300]}
-    # the same frame WITHOUT the bench's own loss kernels (four mean() reductions, three scalar adds, four expand / divide kernels
-    # in backward: ~100 us of torch glue that belongs to this stand-in loss, not to render()): backward is driven by the constant
-    # upstream gradients that loss would produce
-    o = render(1, cam, model, pipe, bg)
-    ups = [torch.full_like(o[k], 1.0 / o[k].numel()) for k in PHASE1_KEYS]
-    del o
-
-    def step_fixed():
+    def step_torch():
         o = render(1, cam, model, pipe, bg)
-        torch.autograd.backward([o[k] for k in PHASE1_KEYS], ups)
+        _phase1_loss_torch(o, *targets).backward()
         return o["render"]
 
-    def eager_fixed():
-        for p in params:
-            p.grad = None
-        step_fixed()
-    for _ in range(5):
-        eager_fixed()
-    el, per = timed(eager_fixed, steps, torch.cuda.synchronize)
-    fx = {"what": "render() forward + autograd backward from constant upstream gradients (no loss kernels)",
-          "eager": {"ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per)}}
-    try:
-        frame = GraphedFrame(step_fixed, warmup=3, zero_grads=params)
-        for _ in range(5):
-            frame.replay()
-        el, per = timed(frame.replay, steps, torch.cuda.synchronize)
-        frame.check()
-        fx["one_graph"] = {"ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per), "self_check": "passed"}
-    except RuntimeError as ex:
-        fx["one_graph"] = {"error": str(ex)[:300]}
-    out["fixed_upstream_gradient"] = fx
+    def measure(step):
+        def eager():
+            for p in params:
+                p.grad = None
+            step()
+        for _ in range(warmup):
+            eager()
+        el, per = timed(eager, steps, torch.cuda.synchronize)
+        res = {"eager": {"value": round(steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4), "step_ms": pct(per)}}
+        try:
+            frame = GraphedFrame(step, warmup=3, zero_grads=params)   # verifies itself (replay / eager work / replay vs eager)
+            for _ in range(5):
+                frame.replay()
+            el, per = timed(frame.replay, steps, torch.cuda.synchronize)
+            frame.check()
+            res["one_graph"] = {"value": round(steps / el, 2), "unit": "frames/s", "ms_per_step": round(el / steps * 1e3, 4),
+                                "step_ms": pct(per), "self_check": "passed"}
+        except RuntimeError as ex:   # never silent: the line says why there is no graph number
+            res["one_graph"] = {"error": str(ex)[:300]}
+        return res
+    out = {"workload": wl["desc"]}
+    out.update(measure(step_fused))
+    out["loss"] = ("phase-1 training loss of train.py:261-265 fused with the rasterizer (gsr_phase1_loss_forward + the blend backward's "
+                   "prologue): `eager` / `one_graph`; the same loss in torch ops: `torch_loss`")
+    out["torch_loss"] = measure(step_torch)
     return out
 
 
@@ -448,9 +456,11 @@ def main_render(a, rank, world, local, dev, rehearsal):
     cam = human_synth.view_camera(body, wl["W"], wl["H"], rank, n_views=8, device=dev)
     bg = torch.zeros(3, device=dev)
     step = parallel.ViewParallelRender(model, _render_pipe(), bg)
+    from mygauhuman_amd.diff_gaussian_rasterization._C import Phase1Loss
+    spec = Phase1Loss(*_phase1_targets(wl["W"], wl["H"], dev, seed=rank))   # every view has its own targets
 
     def one():
-        step(1, cam, _phase1_loss)
+        step(1, cam, lambda o: o["loss"], fused_loss=spec)
 
     def sync():
         if world > 1:

@@ -224,6 +224,44 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
                               float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
                               const float *const *dL_dout_extra, float *dL_dextra, int sh_dtype, gsr_stream_t stream);
 
+/* The training loss render() feeds before the PBR phase (train.py:261-265 with utils/loss_utils.py:20-24), fused:
+ *     L = w_image L1_b(image, gt_image) + w_alpha L2_b(alpha, alpha_target) + w_normal L1_b(normal, gt_normal) + w_axis L1_b(axis, gt_normal)
+ * where L1_b / L2_b are the MEANS over the pixels with bound != 0 (the reference indexes with bound_mask == 1; a mean over n_bound x 3
+ * colour values resp. n_bound alphas).  gsr_phase1_loss_forward reduces the forward's images to the loss value and leaves
+ * (loss, n_bound, 1 / (3 n_bound), 1 / n_bound, the four unweighted terms) in stats[8] on the device -- no host read.
+ * gsr_rasterize_backward_phase1_loss is gsr_rasterize_backward_ex whose blend-backward prologue FORMS this loss's per-pixel
+ * gradient from the same images (bound . w sign(image - gt) / (3 n_bound) etc., times *upstream, the incoming dL/dL: null = 1)
+ * instead of reading it: dL_dpix / dL_ddepths / dL_dalphas and the entries of dL_dout_extra may each be null there (no further
+ * gradient on that image) or carry the gradient of OTHER loss terms (SSIM, LPIPS, ...), which is added.  What it saves per frame
+ * against the same loss in torch ops: four masked reductions, their expand / divide / sign backward kernels and four full-image
+ * gradient tensors written and read (~125 us of a 790 us render() frame at 1024^2, profiles/r3h_render_kernels.txt). */
+typedef struct gsr_phase1_loss {
+  const float *gt_image;      /* [3][H][W] */
+  const float *gt_normal;     /* [3][H][W]: the target of BOTH the normal and the axis image (train.py:263-264) */
+  const float *alpha_target;  /* [H][W]    (bkgd_mask[0]) */
+  const float *bound;         /* [H][W]    != 0 inside bound_mask */
+  float w_image, w_alpha, w_normal, w_axis;
+  int normal_triple, axis_triple; /* which of the six extra colour triples are the normal / the axis image (render(): 0 and 5) */
+  const float *color;         /* the forward's images: [3][H][W] */
+  const float *alpha;         /* [H][W] */
+  const float *extra_images;  /* [18][H][W] */
+  float *stats;               /* device [8], written by gsr_phase1_loss_forward, read by the backward */
+  const float *upstream;      /* device [1]: dL/dloss arriving from autograd (null = 1) */
+} gsr_phase1_loss;
+/* partials: device workspace of at least gsr_phase1_loss_partials() floats */
+size_t gsr_phase1_loss_partials(void);
+int gsr_phase1_loss_forward(int width, int height, const gsr_phase1_loss *loss, float *partials, gsr_stream_t stream);
+int gsr_rasterize_backward_phase1_loss(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+                                       const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
+                                       float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                       const float *viewmatrix, const float *projmatrix, const float *campos, float tan_fovx,
+                                       float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+                                       char *image_buffer, const float *dL_dpix, const float *dL_ddepths, const float *dL_dalphas,
+                                       float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor,
+                                       float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
+                                       int debug, const float *extra_features, int n_extra, const float *const *dL_dout_extra,
+                                       float *dL_dextra, int sh_dtype, const gsr_phase1_loss *loss, gsr_stream_t stream);
+
 /* Fused gradient of L = mean|color - gt| + lambda_alpha * mean (alpha - mask)^2 (train.py:261-262 with the masks set to
  * the whole image): dL_dcolor[3][H][W] = sign(color - gt) / (3 H W), dL_dalpha[H][W] = 2 lambda (alpha - mask) / (H W). */
 int gsr_alpha_mask_loss_backward(int width, int height, const float *color, const float *alpha, const float *gt,
@@ -310,6 +348,25 @@ int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals,
                          const float *Th, int *vert_ids, float *bweights, float *smpl_pts, float *world_pts,
                          float *transforms, float *translation, float *world_normals, char *workspace,
                          size_t workspace_bytes, int grid_is_built, gsr_stream_t stream);
+
+/* gsr_lbs_forward_grid with an EXACT temporal cache of the nearest vertex (the reference searches every
+ * frame, scene/gaussian_model.py:775).  The canonical points move by an optimizer step per iteration, the vertices not at all.
+ * nn_cache (gsr_lbs_nn_cache_bytes(P) bytes, 16-byte aligned, caller-owned, tied to ONE vertex grid) holds per point slot
+ * (x0, id, rho): vertex id is the strict nearest vertex of every point within rho of x0 -- rho = 0.49 x (lower bound on the
+ * distance of every other vertex - distance of id), minus a guard for rounding -- which is a statement about the vertex set, so
+ * it stays true whatever point sits in the slot.  cache_is_valid = 0: full grid search that also makes the entries.
+ * cache_is_valid != 0: every point is checked against its entry, the misses are compacted and searched (and re-centred), the
+ * skinning takes the ids as given: results bit-identical to the search.  `workspace` must hold the BUILT grid
+ * (gsr_lbs_grid_build).  The last 64 bytes of nn_cache are counters: word 1 = searches since the cache was made, word 2 = misses
+ * of the last cached call. */
+size_t gsr_lbs_nn_cache_bytes(int P);
+int gsr_lbs_forward_cached(int P, int V, const float *query, const float *normals, const float *smpl_verts,
+                           const float *weights, const float *lbs_offsets, const float *A_big, const float *A_pose,
+                           const float *off_big, const float *off_shape, const float *off_pose, const float *R,
+                           const float *Th, int *vert_ids, float *bweights, float *smpl_pts, float *world_pts,
+                           float *transforms, float *translation, float *world_normals, char *workspace,
+                           size_t workspace_bytes, char *nn_cache, size_t nn_cache_bytes, int cache_is_valid,
+                           gsr_stream_t stream);
 
 /* Backward of gsr_lbs_forward w.r.t. query, normals, lbs_offsets, A_pose, off_pose (A_big/off_big/off_shape
  * belong to the constant big pose / shape and get no gradient in the reference training loop).

@@ -14,14 +14,23 @@ LIB_PATH = os.path.join(_HERE, "libgsr.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
+
+class Phase1LossStruct(C.Structure):
+    """gsr_phase1_loss (include/gsr.h): the fused phase-1 training loss of render()."""
+    _fields_ = [("gt_image", C.c_void_p), ("gt_normal", C.c_void_p), ("alpha_target", C.c_void_p), ("bound", C.c_void_p),
+                ("w_image", C.c_float), ("w_alpha", C.c_float), ("w_normal", C.c_float), ("w_axis", C.c_float),
+                ("normal_triple", C.c_int), ("axis_triple", C.c_int),
+                ("color", C.c_void_p), ("alpha", C.c_void_p), ("extra_images", C.c_void_p), ("stats", C.c_void_p),
+                ("upstream", C.c_void_p)]
+
 # every symbol include/gsr.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_debug_wave_trace", "gsr_debug_clock_probe",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
-    "gsr_alpha_mask_loss_backward", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
+    "gsr_alpha_mask_loss_backward", "gsr_phase1_loss_partials", "gsr_phase1_loss_forward", "gsr_rasterize_backward_phase1_loss", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
-    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_backward_workgroups", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_sh_view_pack_posed", "gsr_sh_grad_from_views_posed", "gsr_step_status", "gsr_step_finish", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_model_activations_forward", "gsr_model_activations_backward", "gsr_frame_attributes_forward_split", "gsr_frame_attributes_backward_split",
+    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_backward_workgroups", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_lbs_forward_cached", "gsr_lbs_nn_cache_bytes", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_sh_view_pack_posed", "gsr_sh_grad_from_views_posed", "gsr_step_status", "gsr_step_finish", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_model_activations_forward", "gsr_model_activations_backward", "gsr_frame_attributes_forward_split", "gsr_frame_attributes_backward_split",
 ]
 
 GSR_OK = 0
@@ -87,8 +96,12 @@ def _load():
     lib.gsr_rasterize_backward_ex.argtypes = lib.gsr_rasterize_backward.argtypes[:-1] + [fp, C.c_int, C.POINTER(C.c_void_p), fp, C.c_int, vp]
     lib.gsr_rasterize_backward_alpha_mask_loss.argtypes = (lib.gsr_rasterize_backward.argtypes[:24] + [fp, fp, fp, C.c_float] + [fp] * 9
                                                            + [C.c_int, C.c_int, vp])
+    lib.gsr_phase1_loss_partials.restype = sz
+    lib.gsr_phase1_loss_forward.argtypes = [C.c_int, C.c_int, C.POINTER(Phase1LossStruct), fp, vp]
+    lib.gsr_phase1_loss_forward.restype = C.c_int
+    lib.gsr_rasterize_backward_phase1_loss.argtypes = lib.gsr_rasterize_backward_ex.argtypes[:-1] + [C.POINTER(Phase1LossStruct), vp]
     for _n in ("gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
-               "gsr_rasterize_backward_alpha_mask_loss"):
+               "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_backward_phase1_loss"):
         getattr(lib, _n).restype = C.c_int
     lib.gsr_query_state.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_dist2_workspace_bytes.argtypes = [C.c_int]
@@ -100,6 +113,10 @@ def _load():
     lib.gsr_sort_pairs_u32.argtypes = [sz, vp, vp, vp, vp, C.c_int, vp, sz, vp]
     lib.gsr_lbs_forward.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp]
     lib.gsr_lbs_forward_grid.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp, sz, C.c_int, vp]
+    lib.gsr_lbs_forward_cached.argtypes = [C.c_int, C.c_int] + [fp] * 12 + [ip] + [fp] * 6 + [vp, sz, vp, sz, C.c_int, vp]
+    lib.gsr_lbs_forward_cached.restype = C.c_int
+    lib.gsr_lbs_nn_cache_bytes.argtypes = [C.c_int]
+    lib.gsr_lbs_nn_cache_bytes.restype = sz
     lib.gsr_lbs_grid_build.argtypes = [C.c_int, fp, vp, sz, vp]
     lib.gsr_lbs_grid_build.restype = C.c_int
     lib.gsr_lbs_forward_grid.restype = C.c_int

@@ -1217,9 +1217,28 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
   const float pxf = (float)px, pyf = (float)py;
   float T = inside ? a.final_T[p] : 0.f;
   const int lastc = inside ? (int)a.n_contrib[p] : 0;
-  const float dpix0 = inside ? a.dL_dpix[p] : 0.f, dpix1 = inside ? a.dL_dpix[plane + p] : 0.f;
-  const float dpix2 = inside ? a.dL_dpix[2 * plane + p] : 0.f;
-  const float ddep = inside ? a.dL_ddepth[p] : 0.f, dalp = inside ? a.dL_dalpha[p] : 0.f;
+  // image gradients: read (gsr_rasterize_backward_ex), or -- fused phase-1 loss, a.p1 -- FORMED here from the forward's images and
+  // the targets, any gradient that does arrive (other loss terms) added on top
+  const bool fused = a.p1.gt_image != nullptr;  // (kernel-uniform)
+  float dpix0 = (inside && a.dL_dpix) ? a.dL_dpix[p] : 0.f, dpix1 = (inside && a.dL_dpix) ? a.dL_dpix[plane + p] : 0.f;
+  float dpix2 = (inside && a.dL_dpix) ? a.dL_dpix[2 * plane + p] : 0.f;
+  const float ddep = (inside && a.dL_ddepth) ? a.dL_ddepth[p] : 0.f;
+  float dalp = (inside && a.dL_dalpha) ? a.dL_dalpha[p] : 0.f;
+  float p1_s3 = 0.f;  // bound . upstream / (3 n_bound): the scale of the L1 terms at this pixel (0 outside the bound mask)
+  if (fused) {
+    const float up = a.p1.upstream ? a.p1.upstream[0] : 1.f;
+    const float bnd = (inside && a.p1.bound[p] != 0.f) ? up : 0.f;
+    p1_s3 = bnd * a.p1.stats[2];
+    const float s3 = a.p1.w_image * p1_s3, s1 = 2.f * a.p1.w_alpha * bnd * a.p1.stats[3];
+    if (inside) {
+      const float d0 = a.p1.color[p] - a.p1.gt_image[p], d1 = a.p1.color[plane + p] - a.p1.gt_image[plane + p];
+      const float d2 = a.p1.color[2 * plane + p] - a.p1.gt_image[2 * plane + p];
+      dpix0 += d0 > 0.f ? s3 : (d0 < 0.f ? -s3 : 0.f);
+      dpix1 += d1 > 0.f ? s3 : (d1 < 0.f ? -s3 : 0.f);
+      dpix2 += d2 > 0.f ? s3 : (d2 < 0.f ? -s3 : 0.f);
+      dalp += s1 * (a.p1.alpha[p] - a.p1.alpha_target[p]);
+    }
+  }
   float bgd = bg0 * dpix0 + bg1 * dpix1 + bg2 * dpix2;
   uint32_t live_t[NL > 0 ? NL : 1];  // the live triples, ascending (wave-uniform)
   {
@@ -1238,8 +1257,14 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
     s_dx[2 * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dpix2;
 #pragma unroll
     for (int c = 0; c < CL; c++) {
-      const float *img = a.dL_dextra_tri[live_t[c / 3] % (CE / 3)];
-      dxp[c] = inside ? img[(size_t)(c % 3) * plane + p] : 0.f;
+      const uint32_t tri = live_t[c / 3] % (CE / 3);
+      const float *img = a.dL_dextra_tri[tri];
+      dxp[c] = (inside && img) ? img[(size_t)(c % 3) * plane + p] : 0.f;
+      if (fused && inside && (tri == (uint32_t)a.p1.normal_triple || tri == (uint32_t)a.p1.axis_triple)) {  // (wave-uniform test)
+        const float wgt = p1_s3 * (tri == (uint32_t)a.p1.normal_triple ? a.p1.w_normal : a.p1.w_axis);
+        const float d = a.p1.extra_images[(size_t)(3u * tri + (uint32_t)(c % 3)) * plane + p] - a.p1.gt_normal[(size_t)(c % 3) * plane + p];
+        dxp[c] += d > 0.f ? wgt : (d < 0.f ? -wgt : 0.f);
+      }
       bgd += (c % 3 == 0 ? bg0 : (c % 3 == 1 ? bg1 : bg2)) * dxp[c];
       s_dx[(3 + c) * WAVE + (int)(lane & 15u) * 4 + (int)(lane >> 4)] = dxp[c];
     }

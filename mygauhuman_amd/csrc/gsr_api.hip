@@ -625,7 +625,7 @@ struct FusedLoss {  // gsr_rasterize_backward_alpha_mask_loss: the image gradien
 };
 }  // namespace
 
-static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+static int rasterize_backward_impl(const FusedLoss *fused_loss, const gsr_phase1_loss *p1, int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
                               const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
                               float scale_modifier, const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
                               const float *projmatrix, const float *campos, float tan_fovx, float tan_fovy, const int *radii,
@@ -648,9 +648,16 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
     return GSR_EINVAL;
   }
   if (!geom_buffer || !binning_buffer || !image_buffer || !background || !means3D || !viewmatrix || !projmatrix || !campos ||
-      !dL_dpix || !dL_ddepths || !dL_dalphas || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
+      (!p1 && (!dL_dpix || !dL_ddepths || !dL_dalphas)) || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
       !dL_dcov3D) {
     set_error("gsr_rasterize_backward: null required pointer");
+    return GSR_EINVAL;
+  }
+  if (p1 && (n_extra != CE_MAX || !p1->gt_image || !p1->gt_normal || !p1->alpha_target || !p1->bound || !p1->color || !p1->alpha ||
+             !p1->extra_images || !p1->stats || p1->normal_triple < 0 || p1->normal_triple > 5 || p1->axis_triple < 0 ||
+             p1->axis_triple > 5 || p1->axis_triple == p1->normal_triple)) {
+    set_error("gsr_rasterize_backward_phase1_loss: the fused multi-feature pass (n_extra = %d), the forward's images, the targets, "
+              "the bound mask, stats and two different triple indices in 0..5 are required", CE_MAX);
     return GSR_EINVAL;
   }
   if ((shs && !dL_dsh) || (scales && (!rotations || !dL_dscale || !dL_drot))) {
@@ -707,6 +714,14 @@ static int rasterize_backward_impl(const FusedLoss *fused_loss, int P, int D, in
   for (int t = 0; t < CE_MAX / 3; t++) {
     ba.dL_dextra_tri[t] = (n_extra && dL_dout_extra) ? dL_dout_extra[t] : nullptr;
     if (ba.dL_dextra_tri[t]) ba.extra_mask |= 1u << t;
+  }
+  if (p1) {
+    ba.p1 = *p1;
+    ba.extra_mask |= (1u << p1->normal_triple) | (1u << p1->axis_triple);  // live whether or not a further gradient arrives on them
+    if (opt.deterministic || opt.blend_bwd_reduce != 3) {
+      set_error("gsr_rasterize_backward_phase1_loss: built for the default reduction of the fused pass (blend_bwd_reduce = 3, not deterministic)");
+      return GSR_EINVAL;
+    }
   }
   ba.det_rows = det_rows;
   ba.debug_skip_atomics = opt.debug_no_atomics;
@@ -798,7 +813,28 @@ int gsr_rasterize_backward_ex(int P, int D, int M, int R, const float *backgroun
                               float *dL_dopacity, float *dL_dcolor, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                               float *dL_dscale, float *dL_drot, int debug, const float *extra_features, int n_extra,
                               const float *const *dL_dout_extra, float *dL_dextra, int sh_dtype, gsr_stream_t stream) {
-  return rasterize_backward_impl(nullptr, P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales,
+  return rasterize_backward_impl(nullptr, nullptr, P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales,
+                                 scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
+                                 geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic,
+                                 dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, extra_features,
+                                 n_extra, dL_dout_extra, dL_dextra, sh_dtype, stream);
+}
+
+int gsr_rasterize_backward_phase1_loss(int P, int D, int M, int R, const float *background, int width, int height, const float *means3D,
+                                       const float *shs, const float *colors_precomp, const float *alphas, const float *scales,
+                                       float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                       const float *viewmatrix, const float *projmatrix, const float *campos, float tan_fovx,
+                                       float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+                                       char *image_buffer, const float *dL_dpix, const float *dL_ddepths, const float *dL_dalphas,
+                                       float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor,
+                                       float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
+                                       int debug, const float *extra_features, int n_extra, const float *const *dL_dout_extra,
+                                       float *dL_dextra, int sh_dtype, const gsr_phase1_loss *loss, gsr_stream_t stream) {
+  if (!loss) {
+    set_error("gsr_rasterize_backward_phase1_loss: loss descriptor required");
+    return GSR_EINVAL;
+  }
+  return rasterize_backward_impl(nullptr, loss, P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales,
                                  scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
                                  geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic,
                                  dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, extra_features,
@@ -820,7 +856,7 @@ int gsr_rasterize_backward_alpha_mask_loss(int P, int D, int M, int R, const flo
   }
   const FusedLoss fl = {out_color, gt, mask, lambda_alpha};
   // (the three gradient-image arguments only have to be non-null: the kernel does not read them in this mode)
-  return rasterize_backward_impl(&fl, P, D, M, R, background, width, height, means3D, shs, colors_precomp, out_alpha, scales,
+  return rasterize_backward_impl(&fl, nullptr, P, D, M, R, background, width, height, means3D, shs, colors_precomp, out_alpha, scales,
                                  scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
                                  geom_buffer, binning_buffer, image_buffer, out_color, out_alpha, out_alpha, dL_dmean2D, dL_dconic,
                                  dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, nullptr, 0, nullptr,

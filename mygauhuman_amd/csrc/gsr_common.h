@@ -370,6 +370,10 @@ struct BlendBwdArgs {
   const float *ckpt;
   unsigned long long *trace;   // measurement (gsr_debug_wave_trace), as BlendFwdArgs::trace
   int debug_skip_atomics;      // measurement knob "debug_no_atomics" (LDS-fold plain kernel only): results are WRONG when set
+  // fused phase-1 training loss (gsr_rasterize_backward_phase1_loss; 18-channel kernels only): p1.gt_image != null -> the image
+  // gradients are FORMED in the prologue from the forward's images and the targets, and dL_dpix / dL_ddepth / dL_dalpha /
+  // dL_dextra_tri[] (each may then be null) are added on top
+  gsr_phase1_loss p1;
 };
 int launch_reduce_det_rows(int P, const uint32_t *point_offsets, const uint32_t *tiles_touched, const float *det_rows,
                            size_t n_slots, float *grad_rows, hipStream_t stream);

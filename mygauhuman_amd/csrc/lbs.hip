@@ -18,6 +18,7 @@
 #include <float.h>
 
 #include "gsr_common.h"
+#include <stdlib.h>
 
 namespace gsr {
 
@@ -150,7 +151,9 @@ __global__ __launch_bounds__(GRID_BLOCK) void lbs_grid_build_kernel(int V, const
 // exact nearest vertex of q through the grid: rings of cells of growing Chebyshev radius around q's cell; after ring r every
 // unvisited vertex is farther than r*h (r whole cells lie in between), so the search stops once best < that bound.
 // (distance, index) is compared lexicographically: the lowest index wins ties, like the brute-force scan.
-__device__ __forceinline__ int grid_nearest(const char *ws, const float *q, float *best_d2 = nullptr) {
+// other_d2 (optional): a LOWER bound on the squared distance from q to every vertex other than the returned one -- the second-best
+// distance among the vertices examined, or the distance below which the rings left unexamined cannot reach, whichever is smaller.
+__device__ __forceinline__ int grid_nearest(const char *ws, const float *q, float *best_d2 = nullptr, float *other_d2 = nullptr) {
   const GridHeader *g = reinterpret_cast<const GridHeader *>(ws);
   const uint32_t *cells = reinterpret_cast<const uint32_t *>(ws + grid_cells_offset());
   const float4 *sorted = reinterpret_cast<const float4 *>(ws + grid_sorted_offset());
@@ -161,7 +164,7 @@ __device__ __forceinline__ int grid_nearest(const char *ws, const float *q, floa
   const int c2 = grid_cell_coord(q[2], g->bbmin[2], inv_h, d2);
   const int rmax = max(max(max(c0, d0 - 1 - c0), max(c1, d1 - 1 - c1)), max(c2, d2 - 1 - c2));
   const float eps = 1e-3f * h;  // slack for the rounding of the cell assignment
-  float best = FLT_MAX;
+  float best = FLT_MAX, second = FLT_MAX;
   int bid = 0x7fffffff;
   // Rings 0 and 1 in one go: the nine (z, y) rows around q's cell, each ONE contiguous run of the sorted list over x in
   // [c0 - 1, c0 + 1].  All eighteen run bounds are requested before any vertex is looked at: ring by ring (1 + 10 runs, each a
@@ -184,15 +187,22 @@ __device__ __forceinline__ int grid_nearest(const char *ws, const float *q, floa
         const float d = sqdist_exact(v.x, v.y, v.z, q);
         const int id = __float_as_int(v.w);
         if (d < best || (d == best && id < bid)) {
+          second = best;
           best = d;
           bid = id;
+        } else {
+          second = fminf(second, d);
         }
       }
   }
+  float unseen = FLT_MAX;  // squared distance every vertex of the rings NOT examined exceeds (all examined: no bound needed)
   for (int r = 2; r <= rmax; r++) {
     {
       const float lb = (float)(r - 1) * h - eps;
-      if (best < lb * lb) break;
+      if (best < lb * lb) {
+        unseen = lb * lb;
+        break;
+      }
     }
     const int z0 = max(c2 - r, 0), z1 = min(c2 + r, d2 - 1), y0 = max(c1 - r, 0), y1 = min(c1 + r, d1 - 1);
     const int x0 = max(c0 - r, 0), x1 = min(c0 + r, d0 - 1);
@@ -217,14 +227,18 @@ __device__ __forceinline__ int grid_nearest(const char *ws, const float *q, floa
             const float d = sqdist_exact(v.x, v.y, v.z, q);
             const int id = __float_as_int(v.w);
             if (d < best || (d == best && id < bid)) {
+              second = best;
               best = d;
               bid = id;
+            } else {
+              second = fminf(second, d);
             }
           }
         }
       }
   }
   if (best_d2) *best_d2 = best;
+  if (other_d2) *other_d2 = fminf(second, unseen);
   return bid;
 }
 
@@ -240,12 +254,80 @@ __global__ __launch_bounds__(256) void grid_nearest_kernel(int M, const float *q
   if (dist) dist[i] = sqrtf(d2);
 }
 
+// ---- exact temporal cache of the nearest vertex (scene/gaussian_model.py:775 searches every frame) ----
+// The canonical Gaussians move by an optimizer step per iteration; the vertex cloud they are matched against (the subject's
+// big-pose vertices) does not move at all.  An entry (x0, id, rho) says: vertex `id` is the strict nearest vertex of EVERY point
+// within rho of x0.  It is made by a full search that also returns a lower bound D2 on the distance of every other vertex:
+// with d1 = |x0 - v_id|, for |x - x0| = delta the triangle inequality gives |x - v_id| <= d1 + delta and |x - v| >= D2 - delta for
+// every other v, so delta < (D2 - d1) / 2 keeps `id`.  rho = 0.49 (D2 - d1) minus a relative guard for the rounding of the two
+// distances (an entry whose gap is within rounding of zero gets rho = 0 and is searched every frame).  The statement is about the
+// VERTEX SET only: it stays true whatever point sits in slot p (densify / prune may reuse the slot), so the cache is invalidated
+// only when the vertex tensor changes; a slot whose point has moved too far is searched again and re-centred.
+// Two small kernels in front of the skinning kernel, because a per-lane fall-back search inside it would leave every wave waiting for
+// its one or two misses: (1) check every point against its entry, compact the misses (ballot, one atomic per wave); (2) search the
+// misses, dense.  The skinning kernel then takes the ids as given.
+struct NnCacheView {
+  float4 *entry;       // [P] x0, y0, z0, rho  (rho < 0: never searched)
+  int *ids;            // [P]
+  uint32_t *miss;      // [P] points to search this frame
+  uint32_t *count;     // [0] misses of this frame, [1] searches since the cache was made (statistics)
+};
+__device__ __forceinline__ float nn_cache_rho(float best_d2, float other_d2) {
+  if (!(other_d2 < FLT_MAX)) return 1e30f;  // a single vertex
+  const float d1 = sqrtf(best_d2), D2 = sqrtf(other_d2);
+  const float rho = 0.49f * (D2 - d1) - 4e-6f * D2 - 1e-12f;
+  return rho > 0.f ? rho : 0.f;
+}
+__global__ __launch_bounds__(256) void nn_cache_check_kernel(int P, const float *query, NnCacheView c) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  bool miss = false;
+  if (p < P) {
+    const float4 e = c.entry[p];
+    const float dx = query[3 * (size_t)p] - e.x, dy = query[3 * (size_t)p + 1] - e.y, dz = query[3 * (size_t)p + 2] - e.z;
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    miss = !(e.w > 0.f && d2 < e.w * e.w);  // (NaN positions miss, like a negative rho)
+  }
+  const uint64_t m = __ballot(miss);
+  if (m == 0ull) return;
+  const uint32_t lane = lane_id();
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&c.count[0], (uint32_t)__builtin_popcountll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (miss) c.miss[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+}
+__global__ __launch_bounds__(256) void nn_cache_search_kernel(const float *query, const char *grid, NnCacheView c) {
+  const uint32_t n = c.count[0];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t p = c.miss[i];
+    const float q[3] = {query[3 * (size_t)p], query[3 * (size_t)p + 1], query[3 * (size_t)p + 2]};
+    float best, other;
+    const int id = grid_nearest(grid, q, &best, &other);
+    c.ids[p] = id;
+    c.entry[p] = make_float4(q[0], q[1], q[2], nn_cache_rho(best, other));
+  }
+}
+// (the frame's bookkeeping -- statistics += this frame's misses, counter back to zero for the next frame -- is done by thread 0 of
+// the skinning kernel that follows the search: LbsArgs::cache_count)
+__host__ __device__ inline size_t nn_cache_bytes(size_t P) { return P * (sizeof(float4) + 2 * sizeof(uint32_t)) + 64; }
+inline NnCacheView nn_cache_view(char *buf, size_t P) {
+  NnCacheView c;
+  c.entry = reinterpret_cast<float4 *>(buf);
+  c.ids = reinterpret_cast<int *>(buf + P * sizeof(float4));
+  c.miss = reinterpret_cast<uint32_t *>(buf + P * (sizeof(float4) + sizeof(uint32_t)));
+  c.count = reinterpret_cast<uint32_t *>(buf + P * (sizeof(float4) + 2 * sizeof(uint32_t)));
+  return c;
+}
+
 struct LbsArgs {
   int P, V;
   const float *query, *normals, *smpl_verts, *weights, *lbs_offsets, *A_big, *A_pose, *off_big, *off_shape, *off_pose, *R, *Th;
   int *vert_ids;
   float *bweights, *smpl_pts, *world_pts, *transforms, *translation, *world_normals;
   const char *grid;  // vertex grid workspace (GRID variant)
+  const int *given_ids;  // GRID variant: the nearest vertex of every point is already known (the temporal cache): no search
+  float4 *cache_entry;   // GRID variant with a search: also leave (x0, rho) and the id for the temporal cache (null: none)
+  int *cache_ids;
+  uint32_t *cache_count; // given_ids: [0] this frame's misses -> [2], added to [1], reset
 };
 
 __device__ __forceinline__ void inv3(const float *m, float *o) {
@@ -346,7 +428,23 @@ __global__ __launch_bounds__(LBS_BLOCK) void lbs_forward_kernel(const LbsArgs a)
   int bid = 0;
   if (GRID) {
     __syncthreads();  // sAb / sAp
-    if (live) bid = grid_nearest(a.grid, q);
+    if (live) {
+      if (a.given_ids) {
+        bid = a.given_ids[p];
+        if (p == 0 && a.cache_count) {
+          a.cache_count[1] += a.cache_count[0];
+          a.cache_count[2] = a.cache_count[0];
+          a.cache_count[0] = 0u;
+        }
+      } else if (a.cache_entry) {  // a full search that also makes the cache entries
+        float bd, od;
+        bid = grid_nearest(a.grid, q, &bd, &od);
+        a.cache_entry[p] = make_float4(q[0], q[1], q[2], nn_cache_rho(bd, od));
+        a.cache_ids[p] = bid;
+      } else {
+        bid = grid_nearest(a.grid, q);
+      }
+    }
   }
   for (int v0 = 0; !GRID && v0 < a.V; v0 += VTILE) {
     __syncthreads();
@@ -667,9 +765,58 @@ int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals,
   if (!grid_is_built)
     hipLaunchKernelGGL(gsr::lbs_grid_build_kernel, dim3(1), dim3(gsr::GRID_BLOCK), 0, stream, V, smpl_verts, workspace);
   gsr::LbsArgs a = {P, V, query, normals, smpl_verts, weights, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th,
-                    vert_ids, bweights, smpl_pts, world_pts, transforms, translation, world_normals, workspace};
+                    vert_ids, bweights, smpl_pts, world_pts, transforms, translation, world_normals, workspace, nullptr, nullptr,
+                    nullptr, nullptr};
   hipLaunchKernelGGL(gsr::lbs_forward_kernel<true>, dim3((P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK), dim3(gsr::LBS_BLOCK), 0,
                      stream, a);
+  GSR_LAUNCH_CHECK(stream, 0);
+  return GSR_OK;
+}
+
+size_t gsr_lbs_nn_cache_bytes(int P) { return gsr::nn_cache_bytes(P > 0 ? (size_t)P : 1); }
+
+int gsr_lbs_forward_cached(int P, int V, const float *query, const float *normals, const float *smpl_verts, const float *weights,
+                           const float *lbs_offsets, const float *A_big, const float *A_pose, const float *off_big,
+                           const float *off_shape, const float *off_pose, const float *R, const float *Th, int *vert_ids,
+                           float *bweights, float *smpl_pts, float *world_pts, float *transforms, float *translation,
+                           float *world_normals, char *workspace, size_t workspace_bytes, char *nn_cache, size_t nn_cache_bytes,
+                           int cache_is_valid, gsr_stream_t stream_) {
+  if (P < 0 || V <= 0 || (P > 0 && (!query || !smpl_verts || !weights || !A_big || !A_pose || !off_big || !off_shape ||
+                                    !off_pose || !R || !Th || !world_pts))) {
+    gsr::set_error("gsr_lbs_forward_cached: bad arguments");
+    return GSR_EINVAL;
+  }
+  if (P == 0) return GSR_OK;
+  if (!workspace || workspace_bytes < gsr::grid_workspace_bytes(V) || reinterpret_cast<size_t>(workspace) % 16 != 0) {
+    gsr::set_error("gsr_lbs_forward_cached: grid workspace of %zu bytes (16-byte aligned, built by gsr_lbs_grid_build) required, got %zu",
+                   gsr::grid_workspace_bytes(V), workspace_bytes);
+    return GSR_EINVAL;
+  }
+  if (!nn_cache || nn_cache_bytes < gsr::nn_cache_bytes((size_t)P) || reinterpret_cast<size_t>(nn_cache) % 16 != 0) {
+    gsr::set_error("gsr_lbs_forward_cached: cache buffer of %zu bytes (16-byte aligned) required, got %zu", gsr::nn_cache_bytes((size_t)P),
+                   nn_cache_bytes);
+    return GSR_EINVAL;
+  }
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  gsr::NnCacheView c = gsr::nn_cache_view(nn_cache, (size_t)P);
+  gsr::LbsArgs a = {P, V, query, normals, smpl_verts, weights, lbs_offsets, A_big, A_pose, off_big, off_shape, off_pose, R, Th,
+                    vert_ids, bweights, smpl_pts, world_pts, transforms, translation, world_normals, workspace, nullptr, nullptr,
+                    nullptr, nullptr};
+  const dim3 grid((P + gsr::LBS_BLOCK - 1) / gsr::LBS_BLOCK), block(gsr::LBS_BLOCK);
+  if (!cache_is_valid) {  // full search; the entries are made on the way
+    GSR_HIP(gsr::zero_async(c.count, 64, stream));
+    a.cache_entry = c.entry, a.cache_ids = c.ids;
+    hipLaunchKernelGGL(gsr::lbs_forward_kernel<true>, grid, block, 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(gsr::nn_cache_check_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, query, c);
+    // (the misses are a few percent of the points in a training loop: one workgroup per CU strides over them; a launch sized for the
+    // worst case -- every point a miss -- spent 16 us starting 782 workgroups that read one word and left)
+    const int sblocks_full = (P + 255) / 256 < 256 ? (P + 255) / 256 : 256;
+    const int sblocks = getenv("GSR_NN_SBLOCKS") ? atoi(getenv("GSR_NN_SBLOCKS")) : sblocks_full;
+    hipLaunchKernelGGL(gsr::nn_cache_search_kernel, dim3(sblocks), dim3(256), 0, stream, query, workspace, c);
+    a.given_ids = c.ids, a.cache_count = c.count;
+    hipLaunchKernelGGL(gsr::lbs_forward_kernel<true>, grid, block, 0, stream, a);
+  }
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
 }

@@ -287,10 +287,56 @@ def rasterize_gaussians_async(background, means3D, colors, opacity, scales, rota
     return cap, out_color, out_depth, out_alpha, radii, geom, binning, img, out_extra, watch
 
 
+class Phase1Loss:
+    """The loss render() feeds before the PBR phase (train.py:261-265, utils/loss_utils.py:20-24), to be evaluated FUSED with the
+    rasterizer (gsr_phase1_loss_forward / gsr_rasterize_backward_phase1_loss):
+        w_image L1_b(image, gt_image) + w_alpha L2_b(alpha, alpha_target) + w_normal L1_b(normal, gt_normal) + w_axis L1_b(axis, gt_normal)
+    with the means taken over the pixels inside bound_mask.  gt_image, gt_normal: [3,H,W]; alpha_target (bkgd_mask[0]) and
+    bound_mask: [H,W] or [1,H,W] (any dtype; nonzero = inside).  Pass it to gaussian_renderer.render(..., fused_loss=...) (or to
+    GaussianRasterizer.forward_multi): the result carries "loss", and its backward forms the image gradients inside the blend
+    kernel -- no gradient images, no reduction kernels.  Other terms (SSIM, LPIPS, ...) are computed on the images as usual and
+    simply added to it: their image gradients arrive through autograd and are added in the kernel's prologue."""
+
+    def __init__(self, gt_image, gt_normal, alpha_target, bound_mask, w_image=1.0, w_alpha=0.1, w_normal=1.0, w_axis=1.0,
+                 normal_triple=0, axis_triple=5):
+        f = lambda t, planes: t.detach().to(torch.float32).reshape(planes, t.shape[-2], t.shape[-1]).contiguous()  # noqa: E731
+        self.gt_image, self.gt_normal = f(gt_image, 3), f(gt_normal, 3)
+        self.alpha_target, self.bound = f(alpha_target, 1), f(bound_mask, 1)
+        self.weights = (float(w_image), float(w_alpha), float(w_normal), float(w_axis))
+        self.normal_triple, self.axis_triple = int(normal_triple), int(axis_triple)
+        self._partials = None
+
+    def struct(self, color, alpha, out_extra, stats, upstream=None):
+        s = _lib.Phase1LossStruct()
+        s.gt_image, s.gt_normal = self.gt_image.data_ptr(), self.gt_normal.data_ptr()
+        s.alpha_target, s.bound = self.alpha_target.data_ptr(), self.bound.data_ptr()
+        s.w_image, s.w_alpha, s.w_normal, s.w_axis = self.weights
+        s.normal_triple, s.axis_triple = self.normal_triple, self.axis_triple
+        s.color, s.alpha, s.extra_images, s.stats = color.data_ptr(), alpha.data_ptr(), out_extra.data_ptr(), stats.data_ptr()
+        s.upstream = None if upstream is None else upstream.data_ptr()
+        return s
+
+
+def phase1_loss_forward(spec, color, alpha, out_extra):
+    """(loss [0-dim view], stats [8]) of a Phase1Loss over the forward's images; no host synchronisation."""
+    dev = color.device
+    H, W = color.shape[-2], color.shape[-1]
+    for t, shape in ((spec.gt_image, (3, H, W)), (spec.gt_normal, (3, H, W)), (spec.alpha_target, (1, H, W)), (spec.bound, (1, H, W))):
+        if tuple(t.shape) != shape or t.device != dev:
+            raise RuntimeError(f"Phase1Loss: targets must be {H}x{W} images on {dev}")
+    stats = torch.empty((8,), dtype=torch.float32, device=dev)
+    if spec._partials is None or spec._partials.device != dev:
+        spec._partials = torch.empty((int(lib.gsr_phase1_loss_partials()),), dtype=torch.float32, device=dev)
+    st = spec.struct(_f32c(color, "color"), _f32c(alpha, "alpha"), _f32c(out_extra, "out_extra"), stats)
+    with torch.cuda.device(dev):
+        check(lib.gsr_phase1_loss_forward(W, H, C.byref(st), spec._partials.data_ptr(), _stream(dev)), "gsr_phase1_loss_forward")
+    return stats[0], stats
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas,
-                                 debug, out=None, extra=None, dL_dout_extra=None, rows_zeroed=False):
+                                 debug, out=None, extra=None, dL_dout_extra=None, rows_zeroed=False, phase1=None):
     """RasterizeGaussiansBackwardCUDA (DGR/rasterize_points.cu:122-207).
 
     `out` (extension, keyword only in practice): dict name -> preallocated contiguous float32 tensor for any of
@@ -299,7 +345,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     `extra` [P,18], `dL_dout_extra` (extension): the fused multi-feature blend; dL_dout_extra is a list of six [3,H,W]
     gradient images (None = that image received no gradient and costs nothing), or one [18,H,W] tensor."""
     dev = means3D.device
-    P, H, W = means3D.size(0), dL_dout_color.size(1), dL_dout_color.size(2)
+    P, H, W = means3D.size(0), alphas.size(-2), alphas.size(-1)
     M = sh.size(1) if sh.numel() != 0 else 0
     opts = dict(dtype=torch.float32, device=dev)
     # the backward-preprocess kernel writes every element of the tensors it owns (zeros for culled Gaussians)
@@ -340,9 +386,31 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D")
         (sh, sh_dtype), background, alphas = _sh(sh), _f32c(background, "background"), _f32c(alphas, "alphas")
         viewmatrix, projmatrix, campos = _f32c(viewmatrix, "viewmatrix"), _f32c(projmatrix, "projmatrix"), _f32c(campos, "campos")
-        dL_dout_color, dL_dout_depth = _f32c(dL_dout_color, "dL_dout_color"), _f32c(dL_dout_depth, "dL_dout_depth")
-        dL_dout_alpha = _f32c(dL_dout_alpha, "dL_dout_alpha")
+        opt = lambda t, n: None if t is None else _f32c(t, n)  # noqa: E731  (fused loss: an image without a further gradient is None)
+        dL_dout_color, dL_dout_depth = opt(dL_dout_color, "dL_dout_color"), opt(dL_dout_depth, "dL_dout_depth")
+        dL_dout_alpha = opt(dL_dout_alpha, "dL_dout_alpha")
         radii = radii.contiguous()
+        if phase1 is not None:
+            # phase1 = (Phase1Loss, stats [8], upstream dL/dloss (0-dim tensor or None), color [3,H,W], out_extra [18,H,W])
+            spec, stats, upstream, p1_color, p1_extra = phase1
+            if extra is None:
+                raise RuntimeError("the fused phase-1 loss needs the fused multi-feature pass (extra colours)")
+            up = None if upstream is None else upstream.detach().to(torch.float32).reshape(1).contiguous()
+            st = spec.struct(_f32c(p1_color, "color"), alphas, _f32c(p1_extra, "out_extra"), stats, up)
+            with torch.cuda.device(dev):
+                rc = lib.gsr_rasterize_backward_phase1_loss(
+                    P, int(degree), int(M), int(R), ptr(background), W, H, ptr(means3D), ptr(sh), ptr(colors), ptr(alphas),
+                    ptr(scales), float(scale_modifier), ptr(rotations), ptr(cov3D_precomp), ptr(viewmatrix), ptr(projmatrix),
+                    ptr(campos), float(tan_fovx), float(tan_fovy), ptr(radii), geomBuffer.data_ptr(),
+                    binningBuffer.data_ptr(), imageBuffer.data_ptr(), ptr(dL_dout_color), ptr(dL_dout_depth),
+                    ptr(dL_dout_alpha), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
+                    dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                    dL_dsh.data_ptr() if M else None, None if dL_dscales is None else dL_dscales.data_ptr(),
+                    None if dL_drotations is None else dL_drotations.data_ptr(),
+                    int(bool(debug)) | (BWD_ROWS_ZEROED if rows_zeroed else 0), ptr(extra), _lib.N_EXTRA, extra_ptrs,
+                    dL_dextra.data_ptr(), sh_dtype, C.byref(st), _stream(dev))
+            check(rc, "gsr_rasterize_backward_phase1_loss")
+            return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dextra
         with torch.cuda.device(dev):
             rc = lib.gsr_rasterize_backward_ex(
                 P, int(degree), int(M), int(R), ptr(background), W, H, ptr(means3D), ptr(sh), ptr(colors), ptr(alphas),

@@ -114,7 +114,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sync_free=False, will_backward=True):
+                sync_free=False, will_backward=True, loss_spec=None):
         rs = raster_settings
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
@@ -138,40 +138,52 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
         ctx.set_materialize_grads(False)  # untouched images arrive as None in backward, not as zero tensors
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # fused phase-1 training loss (_C.Phase1Loss): its value is one more output; the backward forms its image gradients in-kernel
+        ctx.loss_spec, ctx.loss_stats, loss_out = loss_spec, None, ()
+        if loss_spec is not None:
+            loss, ctx.loss_stats = _C.phase1_loss_forward(loss_spec, color, alpha, out_extra)
+            loss_out = (loss,)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
-                              imgBuffer, alpha, extra)
+                              imgBuffer, alpha, extra, *((color, out_extra) if loss_spec is not None else ()))
         # six separate outputs (views of one [18,H,W] buffer): autograd then hands back one gradient per image -- None for
         # images the loss never touched -- instead of materialising a full 18-plane gradient per slice
-        return (color, radii, depth, alpha) + tuple(out_extra[3 * i:3 * i + 3] for i in range(N_EXTRA // 3))
+        return (color, radii, depth, alpha) + tuple(out_extra[3 * i:3 * i + 3] for i in range(N_EXTRA // 3)) + loss_out
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_alpha, *grad_feats):
         rs = ctx.raster_settings
+        grad_loss = None
+        if ctx.loss_spec is not None:
+            grad_feats, grad_loss = grad_feats[:-1], grad_feats[-1]
         if ctx.watch is not None:
             _C.AsyncCapacity.poll(ctx.saved_tensors[1].device)  # non-blocking here: waiting now would keep the backward kernels off the queue
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha,
-         extra) = ctx.saved_tensors
+         extra) = ctx.saved_tensors[:12]
         H, W = alpha.shape[-2], alpha.shape[-1]
-        # images the loss never touched: one shared read-only zero image per (size, device) instead of a fill per backward
-        grad_out_color = _zero_image(3, H, W, alpha.device) if grad_out_color is None else grad_out_color
-        grad_depth = _zero_image(1, H, W, alpha.device) if grad_depth is None else grad_depth
-        grad_alpha = _zero_image(1, H, W, alpha.device) if grad_alpha is None else grad_alpha
+        phase1 = None
+        if grad_loss is not None:   # the fused loss took part in what is being differentiated: images without a further gradient stay None
+            phase1 = (ctx.loss_spec, ctx.loss_stats, grad_loss, ctx.saved_tensors[12], ctx.saved_tensors[13])
+        else:
+            # images the loss never touched: one shared read-only zero image per (size, device) instead of a fill per backward
+            grad_out_color = _zero_image(3, H, W, alpha.device) if grad_out_color is None else grad_out_color
+            grad_depth = _zero_image(1, H, W, alpha.device) if grad_depth is None else grad_depth
+            grad_alpha = _zero_image(1, H, W, alpha.device) if grad_alpha is None else grad_alpha
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_extra_in) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh, rs.sh_degree, rs.campos,
             geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.debug, out={"lean": True}, extra=extra,
-            dL_dout_extra=list(grad_feats), rows_zeroed=ctx.rows_zeroed)
+            dL_dout_extra=list(grad_feats), rows_zeroed=ctx.rows_zeroed, phase1=phase1)
         if ctx.watch is not None:
             # the whole backward is queued; wait for the FORWARD's overflow flag only (the GPU stays busy with the backward)
             # so that an overflow raises before the optimizer consumes these gradients
             _C.AsyncCapacity.check(ctx.watch)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_extra_in, grad_opacities, grad_scales,
-                grad_rotations, grad_cov3Ds_precomp, None, None, None)
+                grad_rotations, grad_cov3Ds_precomp, None, None, None, None)
 
 
 def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors, opacities, scales, rotations, cov3Ds_precomp,
-                              raster_settings, sync_free=False):
+                              raster_settings, sync_free=False, loss_spec=None):
     """Blend the main colour (SHs or colors_precomp) and up to six extra [P,3] colour sets (a list, or one packed [P,18]
     tensor) in one pass.
     Returns (color, radii, depth, alpha, [image_i [3,H,W] for each extra colour set])."""
@@ -190,8 +202,12 @@ def rasterize_gaussians_multi(means3D, means2D, sh, colors_precomp, extra_colors
     will_backward = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (means3D, means2D, sh, colors_precomp, extra, opacities, scales,
                                                                   rotations, cov3Ds_precomp))
+    if loss_spec is not None and n != 6:
+        raise Exception("rasterize_gaussians_multi: the fused phase-1 loss needs all six extra colour sets (normal and axis among them)")
     out = _RasterizeGaussiansMulti.apply(means3D, means2D, sh, colors_precomp, extra, opacities, scales, rotations, cov3Ds_precomp,
-                                         raster_settings, sync_free, will_backward)
+                                         raster_settings, sync_free, will_backward, loss_spec)
+    if loss_spec is not None:
+        return out[0], out[1], out[2], out[3], list(out[4:4 + n]), out[4 + N_EXTRA // 3]
     return out[0], out[1], out[2], out[3], list(out[4:4 + n])
 
 
@@ -223,10 +239,11 @@ class GaussianRasterizer(nn.Module):
                                    self.raster_settings)
 
     def forward_multi(self, means3D, means2D, opacities, extra_colors, shs=None, colors_precomp=None, scales=None, rotations=None,
-                      cov3D_precomp=None, sync_free=False):
+                      cov3D_precomp=None, sync_free=False, loss_spec=None):
         """Extension: like forward(), plus `extra_colors` (list of 1..6 [P,3] tensors) blended in the same pass.
         Returns (color, radii, depth, alpha, [extra images]).  sync_free=True skips the host read of num_rendered
-        (_C.AsyncCapacity: generous binning capacity, overflow reported at backward / next call)."""
+        (_C.AsyncCapacity: generous binning capacity, overflow reported at backward / next call).
+        loss_spec (a _C.Phase1Loss): the phase-1 training loss evaluated fused with the pass; its value is appended to the result."""
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         has_sr = scales is not None or rotations is not None
@@ -236,4 +253,4 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians_multi(means3D, means2D, empty if shs is None else shs,
                                          empty if colors_precomp is None else colors_precomp, extra_colors, opacities,
                                          empty if scales is None else scales, empty if rotations is None else rotations,
-                                         empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, sync_free)
+                                         empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, sync_free, loss_spec)

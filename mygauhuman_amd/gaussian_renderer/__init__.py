@@ -71,8 +71,11 @@ def _features_of(pc):
 
 
 def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None,
-           return_smpl_rot=False, transforms=None, translation=None, envmap=None):
-    """Render the scene. Background tensor (bg_color) must be on the GPU."""
+           return_smpl_rot=False, transforms=None, translation=None, envmap=None, fused_loss=None):
+    """Render the scene. Background tensor (bg_color) must be on the GPU.
+    fused_loss (extension, default None = the reference's behaviour): a diff_gaussian_rasterization._C.Phase1Loss -- the loss
+    train.py:261-265 forms from this result (bound-masked L1 on image / normal / axis, 0.1 L2 on alpha) evaluated FUSED with the
+    rasterizer: the result then carries "loss" (a 0-dim tensor; add the other terms to it and call backward())."""
     dev = pc.get_xyz.device
     # the gradient holder of the 2D means (:62-66: `zeros_like(...) + 0` and retain_grad()): a zero LEAF that requires grad
     # receives the same .grad without the extra add kernel
@@ -152,12 +155,18 @@ def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
          rendered_axis) = [raster(features[:, 3 * k:3 * k + 3])[0] for k in range(6)]
     else:
         # fused: one preprocess + binning + a 21-channel blend (and one backward) give the same seven images
-        rendered_image, radii, depth, alpha, feats = rasterizer.forward_multi(
+        res = rasterizer.forward_multi(
             means3D=means3D, means2D=means2D, opacities=opacity, extra_colors=features, shs=shs, colors_precomp=colors_precomp,
-            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, sync_free=getattr(pipe, "sync_free_raster", True))
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, sync_free=getattr(pipe, "sync_free_raster", True),
+            loss_spec=fused_loss)
+        rendered_image, radii, depth, alpha, feats = res[:5]
+        fused_value = res[5] if fused_loss is not None else None
         rendered_normal, rendered_world_normal, rendered_albedo, rendered_occlusion, rendered_roughness, rendered_axis = feats
+    if fused_loss is not None and getattr(pipe, "separate_feature_passes", False):
+        raise RuntimeError("render(fused_loss=...): the fused loss rides on the fused multi-feature pass (pipe.separate_feature_passes = False)")
 
-    return {"render": rendered_image, "render_depth": depth, "render_alpha": alpha, "viewspace_points": screenspace_points,
+    extra_out = {} if fused_loss is None else {"loss": fused_value}
+    return {**extra_out, "render": rendered_image, "render_depth": depth, "render_alpha": alpha, "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0, "radii": radii, "transforms": transforms, "translation": translation,
             "correct_Rs": correct_Rs, "normal": rendered_normal, "albedo": rendered_albedo, "occlusion": rendered_occlusion,
             "roughness": rendered_roughness, "world_normal": rendered_world_normal, "render_axis": rendered_axis}

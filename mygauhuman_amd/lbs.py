@@ -225,13 +225,40 @@ class _VertexGridCache:
             self.entries.move_to_end(key)
             return hit[1], True
         ws = torch.empty((lib.gsr_lbs_workspace_bytes(verts.shape[0]),), dtype=torch.uint8, device=verts.device)
-        self.entries[key] = (verts, ws)
+        self.entries[key] = (verts, ws, {})
         if len(self.entries) > self.capacity:
             self.entries.popitem(last=False)
         return ws, False
 
+    def nn_cache(self, verts, P):
+        """The temporal nearest-vertex cache of P query points against this vertex tensor (csrc/lbs.hip "exact temporal cache"):
+        (buffer, valid).  An entry of it is a statement about the vertex set alone, so it lives and dies with the vertex grid --
+        a new vertex tensor (or an in-place change: _version) is a new key and starts empty; densify / prune change P and get a
+        buffer of their own."""
+        key = (verts.data_ptr(), verts._version, tuple(verts.shape), str(verts.device))
+        caches = self.entries[key][2]
+        hit = caches.get(P)
+        if hit is not None:
+            return hit, True
+        if len(caches) >= 4:   # (a model that changes size every few hundred iterations: keep the newest)
+            caches.pop(next(iter(caches)))
+        buf = torch.empty((lib.gsr_lbs_nn_cache_bytes(P),), dtype=torch.uint8, device=verts.device)
+        caches[P] = buf
+        return buf, False
+
+    def nn_cache_stats(self, verts, P):
+        """(misses of the last cached frame, searches since the cache was made) or None -- for tests and tools (synchronises)."""
+        key = (verts.data_ptr(), verts._version, tuple(verts.shape), str(verts.device))
+        e = self.entries.get(key)
+        if e is None or P not in e[2]:
+            return None
+        w = e[2][P][-64:].view(torch.int32)[:3].cpu()
+        return int(w[2]), int(w[1])
+
 
 _GRIDS = _VertexGridCache()
+# exact temporal cache of the nearest vertex (results identical to the search, tests/test_gpu_lbs.py); False: search every frame
+NN_TEMPORAL_CACHE = True
 
 
 class _LBSDeform(torch.autograd.Function):
@@ -265,7 +292,15 @@ class _LBSDeform(torch.autograd.Function):
                     ws, built = _GRIDS.get(smpl_verts)
                 else:
                     ws, built = torch.empty((lib.gsr_lbs_workspace_bytes(V),), dtype=torch.uint8, device=dev), False
-                check(lib.gsr_lbs_forward_grid(*args, ptr(ws), ws.numel(), int(built), stream), "gsr_lbs_forward_grid")
+                if NN_TEMPORAL_CACHE and sv.data_ptr() == smpl_verts.data_ptr():
+                    # frame-to-frame: a point that has not left the ball its entry vouches for keeps its vertex without a search
+                    if not built:
+                        check(lib.gsr_lbs_grid_build(V, ptr(sv), ptr(ws), ws.numel(), stream), "gsr_lbs_grid_build")
+                    nn, valid = _GRIDS.nn_cache(smpl_verts, P)
+                    check(lib.gsr_lbs_forward_cached(*args, ptr(ws), ws.numel(), ptr(nn), nn.numel(), int(valid), stream),
+                          "gsr_lbs_forward_cached")
+                else:
+                    check(lib.gsr_lbs_forward_grid(*args, ptr(ws), ws.numel(), int(built), stream), "gsr_lbs_forward_grid")
             else:
                 check(lib.gsr_lbs_forward(*args, stream), "gsr_lbs_forward")
         ctx.save_for_backward(query_c, normals_c, loff, A_big_c, A_pose_c, ob, os_, op, R_c, vert_ids, w)

@@ -298,3 +298,68 @@ def test_vertex_grid_cache_reuse_and_invalidation(oracle):
     np.testing.assert_array_equal(e, oracle.nearest_vertex(query.cpu().numpy(), verts.cpu().numpy()))
     out = lbs.lbs_deform(query, None, None, d(c["A_big"]), d(c["A_pose"]), z, z, z, d(c["R"]), d(c["Th"]), verts, w, lean=True)
     assert out["bweights"].numel() == 0 and out["smpl_pts"].numel() == 0 and out["world_pts"].shape == (3000, 3)
+
+
+@pytest.mark.parametrize("case", ["walk", "duplicates", "coincident", "single", "slot_reuse"])
+def test_temporal_nearest_vertex_cache_is_exact(oracle, case):
+    """The temporal cache (csrc/lbs.hip "exact temporal cache"; the reference searches every frame, scene/gaussian_model.py:775):
+    ids bit-identical to the full search -- and to the oracle's brute force -- while points WALK ACROSS Voronoi boundaries in
+    steps from far below to far above the typical gap between the two nearest vertices; for vertex clouds with exact ties
+    (duplicates, a zero-extent cloud: every entry has rho = 0 and is searched every frame), for a single vertex (rho unbounded),
+    and when the point slots are refilled with different points (what densify / prune does to a slot)."""
+    from mygauhuman_amd import lbs
+    c = make_case(oracle, 700, 10, 3, False)
+    rng = np.random.default_rng(5)
+    V, P = 3000, 20000
+    verts_np = (rng.uniform(-1, 1, (V, 3)) * np.array([0.9, 0.9, 0.15])).astype(np.float32)
+    if case == "duplicates":
+        verts_np = np.concatenate([verts_np[:750]] * 4).astype(np.float32)
+    elif case == "coincident":
+        verts_np = np.tile(np.array([[0.3, -0.2, 0.1]], np.float32), (64, 1))
+    elif case == "single":
+        verts_np = verts_np[:1]
+    Vn = verts_np.shape[0]
+    verts = torch.from_numpy(verts_np).cuda()
+    d = util.to_dev
+    w, z = d(np.full((Vn, 24), 1 / 24, np.float32)), d(np.zeros((Vn, 3), np.float32))
+    A_big, A_pose, R, Th = d(c["A_big"]), d(c["A_pose"]), d(c["R"]), d(c["Th"])
+    query = torch.from_numpy((verts_np[rng.integers(0, Vn, P)] + rng.normal(0, 0.02, (P, 3))).astype(np.float32)).cuda()
+    # a fixed direction per point: the walk crosses cell after cell of the Voronoi diagram
+    direction = torch.from_numpy(rng.normal(0, 1, (P, 3)).astype(np.float32)).cuda()
+    direction /= direction.norm(dim=1, keepdim=True)
+
+    def ids(cached):
+        old = lbs.NN_TEMPORAL_CACHE
+        lbs.NN_TEMPORAL_CACHE = cached
+        try:
+            return lbs.lbs_deform(query, None, None, A_big, A_pose, z, z, z, R, Th, verts, w, lean=True)["vert_ids"].cpu().numpy()
+        finally:
+            lbs.NN_TEMPORAL_CACHE = old
+    assert lbs.NN_TEMPORAL_CACHE is True   # the default
+    first = ids(True)                      # makes the entries (full search)
+    np.testing.assert_array_equal(first, oracle.nearest_vertex(query.cpu().numpy(), verts_np))
+    changed_total, steps = 0, [0.0, 1e-6, 1e-5, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 3e-2, 1e-4, 1e-4, 0.0]
+    prev = first
+    for k, step in enumerate(steps):
+        query.add_(direction * step)
+        if case == "slot_reuse" and k == 5:   # the slots now hold other points altogether
+            query.copy_(query[torch.randperm(P, device="cuda")])
+        got = ids(True)
+        want = ids(False)
+        np.testing.assert_array_equal(got, want, err_msg=f"step {k} ({step})")
+        if k in (0, 6, len(steps) - 1):
+            np.testing.assert_array_equal(got, oracle.nearest_vertex(query.cpu().numpy(), verts_np))
+        changed_total += int((got != prev).sum())
+        prev = got
+        misses, _ = lbs._GRIDS.nn_cache_stats(verts, P)
+        if case == "walk":
+            if step == 0.0:
+                assert misses < 0.12 * P, (k, misses)      # only the entries whose two nearest vertices tie within the guard
+            if step >= 3e-2:
+                assert misses > 0.5 * P, (k, misses)       # a step of the order of the vertex spacing: most points re-search
+        if case in ("duplicates", "coincident"):
+            assert misses == P                             # exact ties everywhere: rho = 0, nothing is ever trusted
+        if case == "single":
+            assert misses == 0
+    if case in ("walk", "slot_reuse"):
+        assert changed_total > P // 2, "the walk must have crossed Voronoi boundaries for the test to mean anything"

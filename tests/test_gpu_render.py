@@ -516,3 +516,91 @@ def test_forward_only_render_raises_on_the_overflowing_call(oracle, monkeypatch)
     with pytest.raises(RuntimeError, match="exceeded the binning capacity"):
         out["render"].mean().backward()
     _C.AsyncCapacity.check_all()
+
+
+@pytest.mark.parametrize("extra_term", [False, True], ids=["phase1_only", "plus_other_terms"])
+def test_fused_phase1_loss_equals_the_torch_loss_and_its_autograd(oracle, extra_term):
+    """render(fused_loss=Phase1Loss) against the SAME loss written with torch ops the way train.py:261-265 writes it (boolean-mask
+    indexing, utils/loss_utils.py:20-24 means): the value, and the gradient of every leaf and of the screen-space points -- with
+    and without further loss terms on the images (whose gradients arrive through autograd and are added in the kernel's prologue).
+    The torch path itself is pinned against the oracle composition by the test above."""
+    from mygauhuman_amd.diff_gaussian_rasterization._C import Phase1Loss
+    from mygauhuman_amd.gaussian_renderer import render
+    s = _human_scene(oracle, seed=31)
+    model, c = s.model, s.cam_np
+    H, W = c["H"], c["W"]
+    rng = np.random.default_rng(8)
+    d = util.to_dev
+    gt_image, gt_normal = d(rng.uniform(0, 1, (3, H, W)).astype(np.float32)), d(rng.uniform(0, 1, (3, H, W)).astype(np.float32))
+    bkgd = d((rng.uniform(0, 1, (1, H, W)) > 0.4).astype(np.float32))
+    bound_np = np.zeros((1, H, W), np.float32)
+    bound_np[:, H // 6: H - H // 8, W // 5: W - W // 7] = 1.0
+    bound_np *= rng.uniform(0, 1, (1, H, W)) > 0.1   # a ragged mask, not a rectangle
+    bound = d(bound_np)
+    bg = d(np.array([0.1, 0.2, 0.3], np.float32))
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    Wx = d(rng.normal(0, 1, (3, H, W)).astype(np.float32))
+
+    def others(out):   # stand-ins for SSIM / LPIPS / TV: terms that put their own gradients on image, normal, alpha and depth
+        if not extra_term:
+            return 0.0
+        return (0.3 * (out["render"] * Wx).mean() + 0.2 * (out["normal"] ** 2).mean() + 0.1 * out["render_alpha"].mean()
+                + 0.05 * out["render_depth"].mean() + 0.07 * (out["albedo"] * Wx).mean())
+
+    def l1(a, b):
+        return torch.abs(a - b).mean()
+
+    params = list(model.parameters())
+    # ---- torch ops, as the reference writes the loss
+    out = render(1, s.cam, model, pipe, bg)
+    bm = bound[0] == 1
+    Ll1 = l1(out["render"].permute(1, 2, 0)[bm], gt_image.permute(1, 2, 0)[bm])
+    mask_loss = ((out["render_alpha"][bound == 1] - bkgd[bound == 1]) ** 2).mean()
+    normal_loss = l1(out["normal"].permute(1, 2, 0)[bm], gt_normal.permute(1, 2, 0)[bm])
+    axis_loss = l1(out["render_axis"].permute(1, 2, 0)[bm], gt_normal.permute(1, 2, 0)[bm])
+    want_loss = 1.0 * Ll1 + 0.1 * mask_loss + normal_loss + 1.0 * axis_loss
+    (want_loss + others(out)).backward()
+    want = [p.grad.detach().clone() for p in params] + [out["viewspace_points"].grad.detach().clone()]
+    for p in params:
+        p.grad = None
+    # ---- fused
+    spec = Phase1Loss(gt_image, gt_normal, bkgd, bound)
+    out2 = render(1, s.cam, model, pipe, bg, fused_loss=spec)
+    assert out2["loss"].dim() == 0
+    np.testing.assert_allclose(float(out2["loss"].detach()), float(want_loss.detach()), rtol=2e-6)
+    (out2["loss"] + others(out2)).backward()
+    got = [p.grad for p in params] + [out2["viewspace_points"].grad]
+    names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "normal", "albedo", "viewspace")
+    for n, g, w in zip(names, got, want):
+        if float(w.abs().max()) == 0.0:   # (albedo does not enter the phase-1 loss by itself)
+            assert n == "albedo" and not extra_term and (g is None or float(g.abs().max()) == 0.0), n
+            continue
+        assert g is not None, n
+        util.assert_close(f"fused loss d{n}", g.cpu().numpy(), w.cpu().numpy(), tol=2e-5, max_bad_frac=1e-5, outer_tol=2e-4)
+    # an upstream factor on the fused loss (loss scaling) scales its gradients, not the other terms'
+    for p in params:
+        p.grad = None
+    out3 = render(1, s.cam, model, pipe, bg, fused_loss=spec)
+    (2.5 * out3["loss"]).backward()
+    for p in params:
+        p.grad = None if p.grad is None else p.grad / 2.5
+    if not extra_term:
+        for n, p, w in zip(names, params, want):
+            if float(w.abs().max()) == 0.0:
+                continue
+            util.assert_close(f"scaled fused loss d{n}", p.grad.cpu().numpy(), w.cpu().numpy(), tol=2e-5, max_bad_frac=1e-5, outer_tol=2e-4)
+
+
+def test_fused_phase1_loss_with_an_empty_bound_mask_is_zero_and_finite(oracle):
+    from mygauhuman_amd.diff_gaussian_rasterization._C import Phase1Loss
+    from mygauhuman_amd.gaussian_renderer import render
+    s = _human_scene(oracle, seed=32)
+    c = s.cam_np
+    H, W = c["H"], c["W"]
+    z3, z1 = torch.zeros((3, H, W), device="cuda"), torch.zeros((1, H, W), device="cuda")
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+    out = render(1, s.cam, s.model, pipe, util.to_dev(np.zeros(3, np.float32)), fused_loss=Phase1Loss(z3, z3, z1, z1))
+    assert float(out["loss"]) == 0.0
+    out["loss"].backward()
+    for p in s.model.parameters():
+        assert p.grad is None or (bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) == 0.0)
