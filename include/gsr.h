@@ -45,6 +45,11 @@ typedef char *(*gsr_alloc_fn)(void *user, size_t bytes);
 
 /* Library version (major*10000 + minor*100 + patch) and the gfx target it was built for ("gfx950"). */
 int gsr_version(void);
+/* 1 if the library was built with GSR_BUILD_EXPERIMENTS (python -m mygauhuman_amd.build --experiments): the kernels that were built,
+ * measured and NOT adopted (the MFMA reductions, the global -> LDS DMA forward, the 4x4-block forward, round 3's
+ * backward, the "render the longest lists alone" measurement) are then compiled in and selectable through gsr_set_tuning.  The
+ * default build does not contain them, and their knob values are refused. */
+int gsr_has_experiments(void);
 const char *gsr_target_arch(void);
 const char *gsr_last_error(void);
 
@@ -63,10 +68,10 @@ int gsr_get_binning_mode(void);
 /* Knobs (images, radii and gradients never change beyond summation order):
  *   "binning_mode" (= gsr_set_binning_mode);
  *   "blend_fwd_waves" / "blend_bwd_waves" in {1, 2, 4}: waves that cooperate on one 16x16 tile (a lane owns 4 / waves pixels);
- *   "blend_bwd_reduce" in {0, 1, 2, 3}: cross-lane reduction of the backward: 3 = two hops through LDS (default: the per-Gaussian
- *       sums of a quadrant are formed by reader lanes from transposed (r, w) pairs; plain-pass only, other configurations use 0),
- *       0 = v_permlane swaps + DPP on the VALU, 1 = MFMA on the folded rows, 2 = transposed MFMA contraction (1 and 2 are
- *       documented experiments: slower on gfx950);
+ *   "blend_bwd_reduce" in {0, 3}: cross-lane reduction of the backward: 3 = two hops through LDS (default: the per-Gaussian
+ *       sums of a quadrant are formed by reader lanes from transposed (r, w) planes; plain-pass only, other configurations use 0),
+ *       0 = v_permlane swaps + DPP on the VALU.  Experiment builds only (gsr_has_experiments): 1 = MFMA on the folded rows,
+ *       2 = transposed MFMA contraction, 4 = round 3's kernel of the LDS design (all slower on gfx950);
  *   "bucket_hist" in {0, 1}: tile-bucket counting without global atomics (per-workgroup LDS histograms + a dense prefix table,
  *       default) or with one returning global atomic per instance (also taken for tile grids beyond 8192 tiles);
  *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the atomic variant;
@@ -76,9 +81,9 @@ int gsr_get_binning_mode(void);
  *   "blend_segments" in 0 .. 64: 0 = every list is walked whole by the backward; v > 0 (default 8) = a list of at least v / 4 times
  *       the frame's mean list is walked in up to four segments by different waves, each started from a checkpoint of the blend
  *       state the forward writes at the segment boundary (gradients agree with the whole walk to rounding; needs tile_order 1);
- *   "blend_tail_cut" in 0 .. 16 (default 0), "blend_prio" in {0, 1} (default 1; 2..4 are MEASUREMENT ONLY and render wrong
- *       images), "blend_layout" in {0, 1} (1 = experimental forward with a wave per 4x4 pixel block), "blend_fwd_dma" in {0, 1}:
- *       documented experiments, see DESIGN.md section 4;
+ *   "blend_tail_cut" in 0 .. 16 (default 0), "blend_prio" in {0, 1} (default 1); experiment builds only: "blend_prio" 2..4
+ *       (MEASUREMENT ONLY, renders wrong images), "blend_layout" = 1 (forward with a wave per 4x4 pixel block), "blend_fwd_dma" = 1
+ *       (see DESIGN.md section 4);
  *   "tile_cull" in {0, 1}: exact ellipse-vs-tile culling of instances in the tile-bucket back-end (see above);
  *   "deterministic" in {0, 1}: the backward reduces its per-(Gaussian, tile-quadrant) partial sums in a fixed order instead of
  *       with float atomics: run-to-run bit-identical gradients (for tests; costs a 256-byte slot per instance quadrant).

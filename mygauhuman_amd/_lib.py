@@ -25,7 +25,7 @@ class Phase1LossStruct(C.Structure):
 
 # every symbol include/gsr.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "gsr_version", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_debug_wave_trace", "gsr_debug_clock_probe",
+    "gsr_version", "gsr_has_experiments", "gsr_target_arch", "gsr_last_error", "gsr_set_binning_mode", "gsr_get_binning_mode", "gsr_set_tuning", "gsr_set_stream_tuning", "gsr_clear_stream_tuning", "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_debug_wave_trace", "gsr_debug_clock_probe",
     "gsr_mark_visible", "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_query_state",
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_phase1_loss_partials", "gsr_phase1_loss_forward", "gsr_rasterize_backward_phase1_loss", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
@@ -59,6 +59,7 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     vp, fp, ip, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t  # device pointers travel as integers
     lib.gsr_version.restype = C.c_int
+    lib.gsr_has_experiments.restype = C.c_int
     lib.gsr_target_arch.restype = C.c_char_p
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_set_binning_mode.argtypes = [C.c_int]

@@ -43,8 +43,12 @@ def _hipcc():
     return "hipcc"
 
 
-def build(force=False, verbose=False, save_temps=False):
-    objdir = os.path.join(HERE, "build")
+def build(force=False, verbose=False, save_temps=False, experiments=None):
+    """experiments (default: the environment's GSR_BUILD_EXPERIMENTS == "1"): also compile the kernels that were built, measured and
+    not adopted (gsr_has_experiments() reports it; their knob values are refused otherwise)."""
+    if experiments is None:
+        experiments = os.environ.get("GSR_BUILD_EXPERIMENTS") == "1"
+    objdir = os.path.join(HERE, "build_experiments" if experiments else "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(HERE, "..", "include", "gsr.h"),
                                                                                        os.path.abspath(__file__)]
@@ -56,7 +60,7 @@ def build(force=False, verbose=False, save_temps=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_m):
-            cmd = [_hipcc()] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [_hipcc()] + COMMON + (["-DGSR_BUILD_EXPERIMENTS"] if experiments else []) + extra + ["-c", s, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             if verbose:
@@ -66,13 +70,20 @@ def build(force=False, verbose=False, save_temps=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if rebuilt or not os.path.exists(LIB):
+    stamp = os.path.join(objdir, ".linked")
+    if rebuilt or not os.path.exists(LIB) or not os.path.exists(stamp):  # (the stamp: the other flavour may have linked LIB last)
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        for d in ("build", "build_experiments"):
+            other = os.path.join(HERE, d, ".linked")
+            if os.path.exists(other):
+                os.remove(other)
+        open(stamp, "w").close()
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, save_temps="--save-temps" in sys.argv,
+                experiments=True if "--experiments" in sys.argv else None))

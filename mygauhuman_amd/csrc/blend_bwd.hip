@@ -906,6 +906,7 @@ __global__ __launch_bounds__(WAVE) void blend_backward_lds_kernel(const BlendBwd
 }
 
 
+#ifdef GSR_BUILD_EXPERIMENTS  // built, measured, NOT adopted (DESIGN.md section 4 "MFMA"); python -m mygauhuman_amd.build --experiments
 // ---------------------------------------------------------------------------------------------------------------------
 // RED = 2: the per-Gaussian sums over the 64 pixels of a quadrant as a matrix product on the (otherwise idle) matrix pipe.
 //
@@ -1124,6 +1125,8 @@ __global__ __launch_bounds__(WAVE) void blend_backward_mfma_kernel(const BlendBw
     __builtin_amdgcn_wave_barrier();  // keep the next batch's LDS writes behind this batch's reads
   }
 }
+
+#endif  // GSR_BUILD_EXPERIMENTS
 
 // deterministic mode, second step: one thread per (Gaussian, column) adds the Gaussian's slots in index order
 __global__ void reduce_det_rows_kernel(int P, const uint32_t *point_offsets, const uint32_t *tiles_touched, const float *det_rows,
@@ -1586,7 +1589,8 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     else hipLaunchKernelGGL(blend_backward_lds_kernel<true>, dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
-  if (opt.blend_bwd_reduce == 4 && opt.blend_bwd_waves == 4) {  // round 3's instantiation of the same design, kept for A/B this round
+#ifdef GSR_BUILD_EXPERIMENTS
+  if (opt.blend_bwd_reduce == 4 && opt.blend_bwd_waves == 4) {  // round 3's instantiation of the LDS-fold design (A/B against the rewrite)
     hipLaunchKernelGGL((blend_backward_kernel<1, 3, 0>), dim3(slots * 4), dim3(WAVE), 0, stream, a);
     return GSR_OK;
   }
@@ -1602,6 +1606,7 @@ int launch_blend_backward(const BlendBwdArgs &a, const Options &opt, hipStream_t
     }
     return GSR_OK;
   }
+#endif
   switch (opt.blend_bwd_waves) {
     case 1: hipLaunchKernelGGL((blend_backward_kernel<4, 0, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, 0, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;

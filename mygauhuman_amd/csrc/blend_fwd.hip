@@ -311,6 +311,7 @@ __global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_k
   }
 }
 
+#ifdef GSR_BUILD_EXPERIMENTS  // kernels that were built, measured and NOT adopted; python -m mygauhuman_amd.build --experiments
 // ---------------------------------------------------------------------------------------------------------------------
 // EXPERIMENT (knob "blend_fwd_dma" = 1, default off: parity-green and slower -- 191 vs 144 us in the render() frame, see
 // profiles/r3_fwd_dma_experiment.txt): the fused multi-feature forward (CE_MAX extra channels), software-pipelined with
@@ -737,6 +738,8 @@ __global__ __launch_bounds__(WAVE * 4) void blend_forward_sp_kernel(const BlendF
   }
 }
 
+#endif  // GSR_BUILD_EXPERIMENTS
+
 int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t stream) {
   const unsigned tiles = (unsigned)(a.grid_x * a.grid_y);
   if (tiles == 0) return GSR_OK;
@@ -746,18 +749,25 @@ int launch_blend_forward(const BlendFwdArgs &a, const Options &opt, hipStream_t 
       set_error("fused feature blend: exactly %d extra channels with input and output arrays are required", CE_MAX);
       return GSR_EINVAL;
     }
-    if (opt.blend_layout == 1)
+#ifdef GSR_BUILD_EXPERIMENTS
+    if (opt.blend_layout == 1) {
       hipLaunchKernelGGL((blend_forward_sp_kernel<CE_MAX>), dim3(slots * 4), dim3(WAVE * 4), 0, stream, a);
-    else if (opt.blend_fwd_dma)
+      return GSR_OK;
+    }
+    if (opt.blend_fwd_dma) {
       hipLaunchKernelGGL(blend_forward_features_kernel, dim3(slots), dim3(WAVE * 4), 0, stream, a);
-    else
-      hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(slots * (4 / FWD_FEATURE_WPG)), dim3(WAVE * FWD_FEATURE_WPG), 0, stream, a);
+      return GSR_OK;
+    }
+#endif
+    hipLaunchKernelGGL((blend_forward_kernel<1, CE_MAX>), dim3(slots * (4 / FWD_FEATURE_WPG)), dim3(WAVE * FWD_FEATURE_WPG), 0, stream, a);
     return GSR_OK;
   }
+#ifdef GSR_BUILD_EXPERIMENTS
   if (opt.blend_layout == 1 && opt.blend_fwd_waves == 4) {
     hipLaunchKernelGGL((blend_forward_sp_kernel<0>), dim3(slots * 4), dim3(WAVE * 4), 0, stream, a);
     return GSR_OK;
   }
+#endif
   switch (opt.blend_fwd_waves) {
     case 1: hipLaunchKernelGGL((blend_forward_kernel<4, 0>), dim3(tiles), dim3(WAVE), 0, stream, a); break;
     case 2: hipLaunchKernelGGL((blend_forward_kernel<2, 0>), dim3(tiles * 2), dim3(WAVE), 0, stream, a); break;

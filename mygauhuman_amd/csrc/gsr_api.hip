@@ -94,6 +94,19 @@ static int set_option(Options &o, const char *key, int v) {
     set_error("%s must be %s", key, what);
     return GSR_EINVAL;
   };
+#ifdef GSR_BUILD_EXPERIMENTS
+  constexpr bool EXPERIMENTS = true;
+#else
+  constexpr bool EXPERIMENTS = false;
+#endif
+  // knob values that select kernels which were built, measured and not adopted: compiled only with GSR_BUILD_EXPERIMENTS
+  auto experiment = [&](bool is_experimental_value) {
+    if (is_experimental_value && !EXPERIMENTS) {
+      set_error("%s = %d selects an experiment kernel; this libgsr.so was built without them (python -m mygauhuman_amd.build --experiments)", key, v);
+      return true;
+    }
+    return false;
+  };
   if (!strcmp(key, "binning_mode")) {
     if (v != GSR_BINNING_GLOBAL_RADIX && v != GSR_BINNING_TILE_BUCKET) return bad("0 (global radix) or 1 (tile bucket)");
     o.binning_mode = v;
@@ -102,6 +115,7 @@ static int set_option(Options &o, const char *key, int v) {
     o.blend_fwd_waves = v;
   } else if (!strcmp(key, "blend_fwd_dma")) {
     if (v != 0 && v != 1) return bad("0 or 1");
+    if (experiment(v == 1)) return GSR_EINVAL;
     o.blend_fwd_dma = v;
   } else if (!strcmp(key, "blend_bwd_waves")) {
     if (v != 1 && v != 2 && v != 4) return bad("1, 2 or 4");
@@ -119,10 +133,12 @@ static int set_option(Options &o, const char *key, int v) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.tile_cull = v;
   } else if (!strcmp(key, "blend_bwd_reduce")) {
-    if (v < 0 || v > 4) return bad("0 (permlane / DPP folds), 1 (MFMA on folded rows), 2 (transposed MFMA contraction), 3 (LDS folds) or 4 (LDS folds, the round-3 kernel)");
+    if (v < 0 || v > 4) return bad("0 (permlane / DPP folds), 3 (LDS folds: default); experiments: 1 (MFMA on folded rows), 2 (transposed MFMA contraction), 4 (LDS folds, the round-3 kernel)");
+    if (experiment(v == 1 || v == 2 || v == 4)) return GSR_EINVAL;
     o.blend_bwd_reduce = v;
   } else if (!strcmp(key, "blend_layout")) {
-    if (v != 0 && v != 1) return bad("0 (quadrant waves) or 1 (4x4 blocks, four survivors per step)");
+    if (v != 0 && v != 1) return bad("0 (quadrant waves) or 1 (experiment: 4x4 blocks, four survivors per step)");
+    if (experiment(v == 1)) return GSR_EINVAL;
     o.blend_layout = v;
   } else if (!strcmp(key, "blend_tail_cut")) {
     if (v < 0 || v > 16) return bad("0 .. 16 (sixteenths of the busy tiles at the end of the visiting order)");
@@ -131,7 +147,8 @@ static int set_option(Options &o, const char *key, int v) {
     if (v < 0 || v > 64) return bad("0 (never) or the outlier threshold in quarters of the frame's mean list length (4 .. 64)");
     o.blend_segments = v;
   } else if (!strcmp(key, "blend_prio")) {
-    if (v < 0 || v > 4) return bad("0, 1 (issue priority by list length) or 2..4 (MEASUREMENT ONLY: render the longest lists alone)");
+    if (v < 0 || v > 4) return bad("0, 1 (issue priority by list length); experiments: 2..4 (MEASUREMENT ONLY: render the longest lists alone)");
+    if (experiment(v >= 2)) return GSR_EINVAL;
     o.blend_prio = v;
   } else if (!strcmp(key, "debug_no_atomics")) {
     if (v != 0 && v != 1) return bad("0 or 1");
@@ -229,6 +246,13 @@ using namespace gsr;
 extern "C" {
 
 int gsr_version(void) { return 100; }
+int gsr_has_experiments(void) {
+#ifdef GSR_BUILD_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 const char *gsr_target_arch(void) { return "gfx950"; }
 const char *gsr_last_error(void) { return g_error.c_str(); }
 

@@ -316,7 +316,9 @@ __device__ __forceinline__ void list_priority(const uint32_t *order, int n, int 
   if (!enabled || longest == 0u) return;
   // MEASUREMENT ONLY (knob values 2 / 3 / 4: results are WRONG): render nothing but the tiles whose list is within 25 / 50 / 75 % of the
   // longest -- what the longest lists cost when they have the GPU to themselves (profiles/r3d_lone_wave.txt)
+#ifdef GSR_BUILD_EXPERIMENTS
   if (enabled >= 2 && n4 < (uint32_t)(enabled == 2 ? 3 : (enabled == 3 ? 2 : 1)) * longest) __builtin_amdgcn_endpgm();
+#endif
   if (n4 >= 3u * longest) __builtin_amdgcn_s_setprio(3);
   else if (n4 >= 2u * longest) __builtin_amdgcn_s_setprio(2);
   else if (n4 >= longest) __builtin_amdgcn_s_setprio(1);

@@ -262,6 +262,10 @@ static void single_thread_sweep() {
     EXPECT(gsr_set_tuning("deterministic", 0) == GSR_OK);
     for (int red = 0; red <= 3; red++)
       for (int waves = 1; waves <= 4; waves *= 2) {
+        if ((red == 1 || red == 2) && !gsr_has_experiments()) {  // experiment kernels: refused by the default build, with a message
+          EXPECT(gsr_set_tuning("blend_bwd_reduce", red) == GSR_EINVAL && strstr(gsr_last_error(), "experiment") != nullptr);
+          continue;
+        }
         EXPECT(gsr_set_tuning("blend_bwd_reduce", red) == GSR_OK && gsr_set_tuning("blend_bwd_waves", waves) == GSR_OK);
         EXPECT(gsr_set_tuning("blend_fwd_waves", waves) == GSR_OK);
         forward_backward(s, true, red == 3, 1000u, 0, nullptr);

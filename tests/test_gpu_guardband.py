@@ -87,6 +87,7 @@ CONFIGS = [(4, 3, "bucket_tight"), (4, 0, "bucket_tight"), (1, 0, "bucket"), (2,
 def config(request):
     from mygauhuman_amd import _lib
     w, red, binning = request.param
+    util.skip_unless_experiments(red in (1, 2))
     _lib.set_tuning("blend_fwd_waves", w)
     _lib.set_tuning("blend_bwd_waves", w)
     _lib.set_tuning("blend_bwd_reduce", red)

@@ -23,6 +23,7 @@ def _settings(cam, bg, deg):
 def layout(request):
     """Options::blend_layout: 0 = a wave per 8x8 quadrant, 1 = a wave per 4x4 block blending four survivors per step."""
     from mygauhuman_amd import _lib
+    util.skip_unless_experiments(request.param == 1)
     _lib.set_tuning("blend_layout", request.param)
     yield request.param
     _lib.set_tuning("blend_layout", _lib.DEFAULT_BLEND_LAYOUT)

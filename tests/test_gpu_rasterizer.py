@@ -32,6 +32,7 @@ def waves(request):
     blend layout: 0 = a wave per 8x8 quadrant, 1 = a wave per 4x4 block with four survivors per step)"""
     from mygauhuman_amd import _lib
     w, red, layout = request.param
+    util.skip_unless_experiments(red in (1, 2) or layout == 1)
     _lib.set_tuning("blend_fwd_waves", w)
     _lib.set_tuning("blend_bwd_waves", w)
     _lib.set_tuning("blend_bwd_reduce", red)
@@ -321,7 +322,7 @@ def test_deterministic_backward_and_per_stream_knobs(oracle):
     util.assert_close("det vs oracle", a[1][3].cpu().numpy(), want["dL_dmeans3D"], max_bad_frac=2e-4)
 
     # ---- (2) two streams, two threads, different knobs
-    knobs = [dict(binning_mode=0, blend_fwd_waves=1, blend_bwd_waves=2, blend_bwd_reduce=1),
+    knobs = [dict(binning_mode=0, blend_fwd_waves=1, blend_bwd_waves=2, blend_bwd_reduce=1 if util.has_experiments() else 0),
              dict(binning_mode=1, tile_cull=1, blend_fwd_waves=4, blend_bwd_waves=4, blend_bwd_reduce=0, deterministic=1)]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     for st, kn in zip(streams, knobs):

@@ -134,3 +134,16 @@ class GetterOnlyModel:
         if name in GetterOnlyModel._HIDDEN:
             raise AttributeError(name)
         return getattr(object.__getattribute__(self, "_m"), name)
+
+
+def has_experiments():
+    """Was libgsr.so built with GSR_BUILD_EXPERIMENTS (the not-adopted kernels)?  The default build is not; parametrised tests skip
+    the knob values that select them (python -m mygauhuman_amd.build --experiments && pytest -m gpu runs them all)."""
+    from mygauhuman_amd import _lib
+    return bool(_lib.lib.gsr_has_experiments())
+
+
+def skip_unless_experiments(is_experimental):
+    import pytest
+    if is_experimental and not has_experiments():
+        pytest.skip("experiment kernel: not in the default build (python -m mygauhuman_amd.build --experiments)")
