@@ -471,13 +471,18 @@ def main_render(a, rank, world, local, dev, rehearsal):
     sync()
     step.check()
     step.timer.reset()
+    step.ar_timer.reset()
+    if step.compact is not None:
+        step.compact.allgather_ms()
     elapsed, per_step = timed(one, a.steps, sync)
     step.check()
-    ex = step.timer.read_ms()
-    t = torch.tensor([elapsed, float(np.mean(ex)) if ex else 0.0], dtype=torch.float64, device=dev)
+    ex, ar = step.timer.read_ms(), step.ar_timer.read_ms()
+    ag = step.compact.allgather_ms() if step.compact is not None else []
+    t = torch.tensor([elapsed, float(np.mean(ex)) if ex else 0.0, float(np.mean(ar)) if ar else 0.0, float(np.mean(ag)) if ag else 0.0],
+                     dtype=torch.float64, device=dev)
     if world > 1:
         parallel.all_reduce_(t, dist.ReduceOp.MAX)
-    elapsed, exchange_ms = float(t[0]), float(t[1])
+    elapsed, exchange_ms, allreduce_ms, allgather_ms = float(t[0]), float(t[1]), float(t[2]), float(t[3])
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         out = {"metric": "frames/sec render() fwd+bwd @1024^2, 200k articulated Gaussians (view-parallel training step)",
@@ -493,7 +498,8 @@ def main_render(a, rank, world, local, dev, rehearsal):
                           + (" (compact SH: all-gather + all-reduce)" if step.compact is not None else " (one all-reduce)"),
                           "P": P, "width": wl["W"], "height": wl["H"], "leaves": list(step.leaves),
                           "backend": (dist.get_backend() if world > 1 else None)},
-               "step_ms": pct(per_step), "exchange_ms": round(exchange_ms, 4), "step_compute_ms": round(ms - exchange_ms, 4),
+               "step_ms": pct(per_step), "exchange_ms": round(exchange_ms, 4), "allreduce_ms": round(allreduce_ms, 4),
+               "allgather_ms": round(allgather_ms, 4), "step_compute_ms": round(ms - exchange_ms, 4),
                "splatted_gaussians_per_s": round(world * a.steps / elapsed * P, 1)}
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -579,9 +585,14 @@ def main():
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     if sc.step is not None:
         sc.step.timer.reset()
+        sc.step.ar_timer.reset()
+        if sc.step.compact is not None:
+            sc.step.compact.allgather_ms()
     elapsed, per_step = timed(sc.one_step, a.steps, sync)
     clock_after = _lib.clock_probe(1024, 1 << 19, dev)[0]
     ex_ms = sc.step.timer.read_ms() if sc.step is not None else []
+    ar_ms = sc.step.ar_timer.read_ms() if sc.step is not None else []
+    ag_ms = sc.step.compact.allgather_ms() if (sc.step is not None and sc.step.compact is not None) else []
     # stage times at the settled clock (the pass above ran on a cold GPU and only chose the kernel to time)
     dom_ms, dom_n = _lib.profile_read()[dominant]
     _lib.profile_enable(_lib.PROF_STAGES)
@@ -591,12 +602,13 @@ def main():
     stage_ms = {k: (ms / n if n else 0.0) for k, (ms, n) in _lib.profile_read().items()}
     _lib.profile_enable([])
     ls = sc.list_stats()  # (synchronises; after the timed region)
-    t = torch.tensor([elapsed, float(np.mean(ex_ms)) if ex_ms else 0.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(np.mean(ex_ms)) if ex_ms else 0.0, float(np.mean(ar_ms)) if ar_ms else 0.0,
+                      float(np.mean(ag_ms)) if ag_ms else 0.0], dtype=torch.float64, device=dev)
     Rt = torch.tensor([float(ls["instances_after_tile_cull"])], dtype=torch.float64, device=dev)
     if world > 1:
         parallel.all_reduce_(t, dist.ReduceOp.MAX)
         parallel.all_reduce_(Rt, dist.ReduceOp.SUM)
-    elapsed, exchange_ms = float(t[0]), float(t[1])
+    elapsed, exchange_ms, allreduce_ms, allgather_ms = float(t[0]), float(t[1]), float(t[2]), float(t[3])
     sc.check()
 
     out = None
@@ -657,6 +669,10 @@ def main():
             # N > 1: HIP events around the collectives of every step (max over ranks of the per-rank mean) and what is left of the
             # step -- so that a scaling run says where its time went
             "exchange_ms": round(exchange_ms, 4) if world > 1 else None,
+            # the two collectives travel at the same time (all-gather: side stream, its own communicator): exchange_ms is what the
+            # compute stream spends on both; allreduce_ms / allgather_ms are each one's own span (max over ranks of the per-rank mean)
+            "allreduce_ms": round(allreduce_ms, 4) if world > 1 else None,
+            "allgather_ms": round(allgather_ms, 4) if world > 1 else None,
             "step_compute_ms": round(ms_per_step - exchange_ms, 4) if world > 1 else None,
             "splatted_gaussians_per_s": round(fps * P, 1),
             "instances_per_s": round(float(Rt.item()) * a.steps / elapsed, 1),

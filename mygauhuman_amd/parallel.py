@@ -197,7 +197,9 @@ class CompactShExchange:
     The send buffer is a tensor of its own (the pack kernel writes it; nothing is copied) and the receive buffer is
     [world][stride]: a plain out-of-place all_gather_into_tensor -- no aliasing of send and receive memory."""
 
-    def __init__(self, P, M, device, group=None, posed=False):
+    def __init__(self, P, M, device, group=None, posed=False, side_stream=None):
+        """side_stream: None = a side stream + communicator of its own when world > 1 on a device backend; True forces them (the
+        one-rank RCCL smoke test); False = everything on the compute stream."""
         self.P, self.M, self.group, self.posed = int(P), int(M), group, bool(posed)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         P = self.P
@@ -215,8 +217,21 @@ class CompactShExchange:
         else:
             self.grad = torch.empty((P, self.M, 3), dtype=torch.float32, device=device)
         self.form = "tensor"
+        # The all-gather runs on a SIDE stream through a communicator of its own (SURVEY.md section 8e "overlap"): its payload is
+        # final long before the all-reduce's -- after the attribute kernel's backward in the articulated path, after the backward
+        # preprocess in the static one -- so it is issued there (exchange_async) and travels under what the compute stream still has
+        # to do (LBS / activation backward, the bucket copy) and under the all-reduce itself; two collectives in flight at once need
+        # two communicators.  wait() orders the compute stream behind it right before the reconstruction reads the blocks.
+        # Host-staged backends (gloo rehearsals, CPU tests) are synchronous by nature: exchange_async() completes before it returns.
+        self.side, self.ag_group, self._ag_done, self._ag_timing = None, group, None, []
         if self.world > 1:
             self.form = collective_selftest(torch.device(device), group)
+        want_side = (self.world > 1) if side_stream is None else bool(side_stream)
+        if want_side and dist.is_available() and dist.is_initialized():
+            if torch.device(device).type == "cuda" and not _staged(self.mine, group):
+                self.side = torch.cuda.Stream(device=device)
+                self.ag_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group),
+                                               backend=dist.get_backend(group))
 
     def pack(self, session, campos):
         """Static path: fill this rank's block from the session's last backward (its raw dL_dcolor + the forward's clamp bits)."""
@@ -237,6 +252,47 @@ class CompactShExchange:
     def local(self):
         """No exchange (single process, or an un-reduced step): this rank's block becomes view 0; reconstruct with n_views=1."""
         self.gathered[0].copy_(self.mine)
+
+    def exchange_async(self, timing=False):
+        """Issue the all-gather of this rank's block NOW (the block must be packed): on the side stream, behind everything the
+        current stream has queued so far.  Follow with wait() before reconstruct() / max_radii()."""
+        if self.side is None:
+            self.exchange()
+            return
+        cur = torch.cuda.current_stream(self.mine.device)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            e0 = e1 = None
+            if timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
+            if self.form == "tensor":
+                dist.all_gather_into_tensor(self.gathered.view(-1), self.mine, group=self.ag_group)
+            else:
+                parts = [torch.empty_like(self.mine) for _ in range(self.world)]
+                dist.all_gather(parts, self.mine, group=self.ag_group)
+                self.gathered.copy_(torch.stack(parts))
+            if timing:
+                e1.record(self.side)
+                self._ag_timing.append((e0, e1))
+            self._ag_done = torch.cuda.Event()
+            self._ag_done.record(self.side)
+        # (the block and the receive buffer are used by the side stream: the caching allocator must not hand them on early --
+        # both are owned by this object for its lifetime, nothing to record)
+
+    def wait(self):
+        """Order the current stream behind the all-gather issued by exchange_async()."""
+        if self._ag_done is not None:
+            torch.cuda.current_stream(self.mine.device).wait_event(self._ag_done)
+            self._ag_done = None
+
+    def allgather_ms(self):
+        """Per-step all-gather times on the side stream since the last call (synchronises on the last one)."""
+        t, self._ag_timing = self._ag_timing, []
+        if not t:
+            return []
+        t[-1][1].synchronize()
+        return [a.elapsed_time(b) for a, b in t]
 
     def exchange(self):
         if self.world <= 1:
@@ -341,7 +397,8 @@ class ViewParallelStep:
         self.pending = deque()   # (step index, pinned uint32 [ranks overflowed, R, own flag], event)
         self._pinned, self._events = [], []
         self._scale = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.timer = ExchangeTimer()
+        self.timer = ExchangeTimer()      # the whole exchange as the compute stream sees it (all-reduce + waiting for the all-gather)
+        self.ar_timer = ExchangeTimer()   # the all-reduce alone; the all-gather times itself on its side stream (compact.allgather_ms)
         if world > 1:
             collective_selftest(dev, group)
 
@@ -408,9 +465,14 @@ class ViewParallelStep:
             self.timer.begin(dev)
             if reduce:
                 if self.compact is not None:
+                    # the all-gather (side stream, own communicator) and the all-reduce (this stream) travel at the same time
                     self.compact.pack(s, cam["campos"])
-                    self.compact.exchange()
+                    self.compact.exchange_async(timing=True)
+                self.ar_timer.begin(dev)
                 all_reduce_(b.flat, dist.ReduceOp.SUM, self.group)
+                self.ar_timer.end(dev)
+                if self.compact is not None:
+                    self.compact.wait()
             else:
                 # an un-reduced step of a multi-rank job keeps its gradients local, but the ranks still AGREE on the overflow word
                 # (one 4-byte all-reduce): every rank raises BinningOverflow at the same call, or none does -- a rank that raised
@@ -447,11 +509,20 @@ class _DetachedShModel:
 
 
 class _ShSink:
+    """What the attribute kernel's backward hands to the compact exchange (attributes.sh_gradient_sink).  With `early` set (the
+    exchange object, the camera position and the radii of this view) the block is packed and its all-gather issued RIGHT THERE, in
+    the middle of autograd's backward: it travels under the LBS / activation backward kernels that follow."""
+
     def __init__(self):
-        self.got = None
+        self.got, self.early, self.sent = None, None, False
 
     def collect(self, colors, g_colors, means_view):
         self.got = (colors, g_colors, means_view)
+        if self.early is not None:
+            ex, campos, radii = self.early
+            ex.pack_posed(colors, g_colors, means_view, campos, radii)
+            ex.exchange_async(timing=True)
+            self.sent = True
 
 
 class ViewParallelRender:
@@ -516,7 +587,8 @@ class ViewParallelRender:
         self.pending = deque()
         self._pinned, self._events = [], []
         self._scale = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.timer = ExchangeTimer()
+        self.timer = ExchangeTimer()      # the whole exchange as the compute stream sees it (all-reduce + waiting for the all-gather)
+        self.ar_timer = ExchangeTimer()   # the all-reduce alone; the all-gather times itself on its side stream (compact.allgather_ms)
         self._view = _DetachedShModel(model) if self.compact is not None else model
         if world > 1 and self.compact is None:
             collective_selftest(dev, group)
@@ -608,6 +680,8 @@ class ViewParallelRender:
             with attributes.sh_gradient_sink(sink):
                 out = render(iteration, camera, self._view, self.pipe, self.bg, **render_kw)
                 loss = loss_fn(out)
+                if sink is not None and self.world > 1 and reduce:
+                    sink.early = (self.compact, camera.camera_center, out["radii"])
                 loss.backward()
         except _RasterC.BinningCapacityExceeded:
             overflowed = True   # this view rendered only the background: it contributes zeros and one count
@@ -639,8 +713,9 @@ class ViewParallelRender:
                 if sink.got is None:
                     raise RuntimeError("ViewParallelRender: the compact SH exchange needs render()'s python SH path "
                                        "(pipe.convert_SHs_python = True, no override_color)")
-                colors, g_colors, means_view = sink.got
-                self.compact.pack_posed(colors, g_colors, means_view, camera.camera_center, out["radii"])
+                if not sink.sent:
+                    colors, g_colors, means_view = sink.got
+                    self.compact.pack_posed(colors, g_colors, means_view, camera.camera_center, out["radii"])
             else:
                 self.max_radii.copy_(out["radii"])
         host = self._pinned.pop() if self._pinned else torch.zeros(3, dtype=torch.int32).pin_memory()
@@ -648,11 +723,15 @@ class ViewParallelRender:
         n_views = self.world if (self.world > 1 and reduce) else 1
         if n_views > 1:
             self.timer.begin(dev)
-            if self.compact is not None:
-                self.compact.exchange()
+            if self.compact is not None and not (sink is not None and sink.sent):
+                self.compact.exchange_async(timing=True)   # (an overflowed view, or nothing reached the sink: zeros / late pack)
+            self.ar_timer.begin(dev)
             all_reduce_(b.flat, dist.ReduceOp.SUM, self.group)
+            self.ar_timer.end(dev)
             if self.compact is None:
                 all_reduce_(self.max_radii, dist.ReduceOp.MAX, self.group)
+            if self.compact is not None:
+                self.compact.wait()
             self.timer.end(dev)
         else:
             if self.world > 1:

@@ -35,6 +35,21 @@ dist.all_gather_into_tensor(ex.gathered.view(-1), ex.mine)       # what exchange
 y = (b.flat * 2).sum()                                             # compute-stream work ordered after the collectives
 torch.cuda.synchronize()
 assert torch.equal(b.flat, want) and torch.equal(ex.gathered[0], ex.mine) and float(y) == float((want * 2).sum())
+# the exchange AS ISSUED since round 4: all-gather on a side stream through a communicator of its own, the all-reduce on the compute
+# stream at the same time, wait() before the blocks are read -- ordering against compute-stream work on BOTH sides of it, 20 rounds
+ex2 = parallel.CompactShExchange(1000, 16, dev, posed=True, side_stream=True)
+assert ex2.side is not None and ex2.ag_group is not None
+for k in range(20):
+    ex2.mine.copy_(torch.arange(ex2.stride, dtype=torch.float32, device=dev) + float(k))   # "the pack": compute-stream work
+    ex2.exchange_async(timing=True)
+    b.flat.copy_(want + float(k))
+    parallel.all_reduce_(b.flat)                                   # travels while the all-gather is in flight
+    ex2.wait()
+    got = ex2.gathered[0].clone()                                  # compute-stream read after wait()
+    torch.cuda.synchronize()
+    assert torch.equal(got, torch.arange(ex2.stride, dtype=torch.float32, device=dev) + float(k)), k
+    assert torch.equal(b.flat, want + float(k)), k
+assert len(ex2.allgather_ms()) == 20
 print("RCCL_SMOKE_OK", form)
 dist.destroy_process_group()
 """
