@@ -740,31 +740,45 @@ __global__ __launch_bounds__(WAVE) void blend_backward_lds_kernel(const BlendBwd
   // hop 1, reader side: r of Gaussian `row` in plane row, w in plane 4 + row; four consecutive lanes = this reducer's pixels
   const float4 *rd_r = reinterpret_cast<const float4 *>(&s_rw[row * WAVE + kcol * 4u]);
   const float4 *rd_w = reinterpret_cast<const float4 *>(&s_rw[(4u + row) * WAVE + kcol * 4u]);
-  // second hop: which (half, value) column k < 9 of the gradient row this lane owns
+  // second hop: column k < 9 of the gradient row this lane owns
   //   column k: 0 r dx (lower qb) 1 r dy (upper qa) 2 r dx^2 (lower qc) 3 r dx dy (upper qb) 4 r dy^2 (upper qc)
   //             5 r (lower qa)    6 red (lower ka)  7 green (upper ka)   8 blue (lower kb)
-  constexpr uint64_t HALF_OF_K = 0x000000000000009Aull;  // bit k: upper half
-  constexpr uint64_t VAL_OF_K = 0x0000000433021201ull;   // nibble k: which of qa..kb (0..4)
+  // Where the eight partial sums of gradient-row column k of a reducer row live (floats from the row's base, H2_ROW floats per
+  // row): found by search against the LDS banking rules of MI355X_MICROARCH.md -- 16-byte reads are served in groups of 16 lanes
+  // that MIX two reducer rows, 64 banks; 4-byte stores in groups of 32 lanes, 32 banks -- so that neither the readers' two
+  // 16-byte reads nor the five stores meet a bank conflict (round 3's dense [row][half][value][8] rows put columns 5 and 7 -- and
+  // rows 0 and 1 -- on the same banks: 8 extra LDS cycles on each of the two reads, 8.6 M conflict cycles per launch,
+  // profiles/r4a_pmc.csv).  An upper-half lane's value lands 8 floats after its lower-half partner's, so ONE base register serves
+  // all five stores: lower values qa qb qc ka kb -> columns 5 0 2 6 8, upper -> 1 3 4 7 (its kb is the same sum: not stored).
+  constexpr uint32_t H2_ROW = 112;
+  constexpr uint64_t H2_P = (20ull) | (8ull << 7) | (40ull << 14) | (28ull << 21) | (48ull << 28) | (0ull << 35) | (72ull << 42) |
+                            (80ull << 49) | (60ull << 56);  // offset of column k, 7 bits each
+  static_assert(4 * H2_ROW * 4 <= RW_BYTES, "hop 2 fits the reduction buffer");
   const uint32_t k9 = kcol < 9u ? kcol : 0u;
-  const uint32_t hk = (uint32_t)((HALF_OF_K >> k9) & 1u), vk = (uint32_t)((VAL_OF_K >> (4u * k9)) & 0xFu);
-  const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[((row * 2u + hk) * 5u + vk) * 8u]);
-  float *t2 = &s_rw[((row * 2u + (upper ? 1u : 0u)) * 5u) * 8u + jj];
+  const float4 *src8 = reinterpret_cast<const float4 *>(&s_rw[row * H2_ROW + (uint32_t)((H2_P >> (7u * k9)) & 127u)]);
+  float *t2 = &s_rw[row * H2_ROW + (upper ? 8u : 0u) + jj];
 
+  // the list entry of the NEXT batch is requested a batch ahead, and a batch's three 16-byte record words in ONE round trip (the
+  // middle word used to wait for the box test): one exposed memory round trip per batch instead of three dependent ones
+  uint32_t id_next = 0;
+  if (skip + (int)lane < walk_end) id_next = a.point_list[range.y - 1 - (skip + (int)lane)];
   for (int base = skip; base < walk_end; base += WAVE) {
     // ---- fetch 64 entries (from the back), cull, compact into LDS in back-to-front order
     const int idx = base + (int)lane;
     bool keep = false;
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
     float l255 = 0.f;
-    uint32_t id = 0;
+    const uint32_t id = id_next;
     if (idx < walk_end) {
-      id = a.point_list[range.y - 1 - idx];
       const float4 *src = reinterpret_cast<const float4 *>(a.recs + id);
       r0 = src[0];
+      r1 = src[1];
       r2 = src[2];
+    }
+    if (idx + WAVE < walk_end) id_next = a.point_list[range.y - 1 - (idx + WAVE)];
+    if (idx < walk_end) {
       keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
       if (keep) {  // second, exact filter: ellipse {alpha >= 1/255} against the wave's pixel rectangle
-        r1 = src[1];
         l255 = __builtin_amdgcn_logf(255.0f * r1.y);
         keep = ellipse_hits_rect_fast(r0.x, r0.y, r0.z, r0.w, r1.x, l255, rx0, rx1, ry0, ry1);
       }
@@ -876,13 +890,13 @@ __global__ __launch_bounds__(WAVE) void blend_backward_lds_kernel(const BlendBwd
         const float qc = upper ? c2 : qb * dxr;
         const float ka = pack_halves(c[3], c[4], upper);
         const float kb = c[5] + dpp_f<0x128>(c[5]);
-        // second hop: lane (row, half, jx) leaves its five half-row values as [row][half][value][jx]; lane (row, column k < 9) reads
-        // the eight jx of ITS (half, value) -- two 16-byte loads -- adds them and owns column k of the Gaussian's gradient row
-        t2[0] = qa;
-        t2[8] = qb;
-        t2[16] = qc;
-        t2[24] = ka;
-        t2[32] = kb;
+        // second hop: lane (row, half, jx) leaves its half-row values at [row][column][jx] (layout: H2_P above); lane (row, column
+        // k < 9) reads the eight jx of ITS column -- two 16-byte loads -- adds them and owns column k of the Gaussian's gradient row
+        t2[0] = qa;    // lower: column 5 (r)        upper: column 1 (r dy)
+        t2[20] = qb;   // lower: column 0 (r dx)     upper: column 3 (r dx dy)
+        t2[40] = qc;   // lower: column 2 (r dx^2)   upper: column 4 (r dy^2)
+        t2[72] = ka;   // lower: column 6 (red)      upper: column 7 (green)
+        if (!upper) t2[60] = kb;   // column 8 (blue)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

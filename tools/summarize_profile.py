@@ -29,7 +29,7 @@ def main(tag, src="gpurun_out", dst="profiles"):
                             f"{float(r['AverageNs']) / 1e3:.2f}", r["Percentage"]])
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     dur = defaultdict(lambda: [0.0, 0])
-    for part in ("fetch", "write", "sq"):
+    for part in ("fetch", "write", "sq", "lds"):
         for path in glob.glob(os.path.join(src, f"{tag}_pmc_{part}", "*", "*_counter_collection.csv")):
             seen = set()
             for r in csv.DictReader(open(path)):
