@@ -360,7 +360,7 @@ int gsr_lbs_forward_grid(int P, int V, const float *query, const float *normals,
  * (x0, id, rho): vertex id is the strict nearest vertex of every point within rho of x0 -- rho = 0.49 x (lower bound on the
  * distance of every other vertex - distance of id), minus a guard for rounding -- which is a statement about the vertex set, so
  * it stays true whatever point sits in the slot.  cache_is_valid = 0: full grid search that also makes the entries.
- * cache_is_valid != 0: every point is checked against its entry, the misses are compacted and searched (and re-centred), the
+ * cache_is_valid != 0: one kernel checks every point against its entry and searches (and re-centres) the misses, the
  * skinning takes the ids as given: results bit-identical to the search.  `workspace` must hold the BUILT grid
  * (gsr_lbs_grid_build).  The last 64 bytes of nn_cache are counters: word 1 = searches since the cache was made, word 2 = misses
  * of the last cached call. */

@@ -18,7 +18,6 @@
 #include <float.h>
 
 #include "gsr_common.h"
-#include <stdlib.h>
 
 namespace gsr {
 
@@ -263,13 +262,13 @@ __global__ __launch_bounds__(256) void grid_nearest_kernel(int M, const float *q
 // distances (an entry whose gap is within rounding of zero gets rho = 0 and is searched every frame).  The statement is about the
 // VERTEX SET only: it stays true whatever point sits in slot p (densify / prune may reuse the slot), so the cache is invalidated
 // only when the vertex tensor changes; a slot whose point has moved too far is searched again and re-centred.
-// Two small kernels in front of the skinning kernel, because a per-lane fall-back search inside it would leave every wave waiting for
-// its one or two misses: (1) check every point against its entry, compact the misses (ballot, one atomic per wave); (2) search the
-// misses, dense.  The skinning kernel then takes the ids as given.
+// One small kernel in front of the skinning kernel (a per-lane fall-back search inside it would leave every wave waiting for its one
+// or two misses): check every point against its entry, compact the workgroup's misses, search them.  The skinning kernel then takes
+// the ids as given.
 struct NnCacheView {
   float4 *entry;       // [P] x0, y0, z0, rho  (rho < 0: never searched)
   int *ids;            // [P]
-  uint32_t *miss;      // [P] points to search this frame
+  uint32_t *miss;      // [P] (unused since the check and the search became one kernel; kept in the buffer layout)
   uint32_t *count;     // [0] misses of this frame, [1] searches since the cache was made (statistics)
 };
 __device__ __forceinline__ float nn_cache_rho(float best_d2, float other_d2) {
@@ -278,7 +277,15 @@ __device__ __forceinline__ float nn_cache_rho(float best_d2, float other_d2) {
   const float rho = 0.49f * (D2 - d1) - 4e-6f * D2 - 1e-12f;
   return rho > 0.f ? rho : 0.f;
 }
-__global__ __launch_bounds__(256) void nn_cache_check_kernel(int P, const float *query, NnCacheView c) {
+// ONE kernel (round 4, after measuring the two-kernel form: a separate search launch cost 17 us per frame even with an empty miss
+// list): every thread checks its point; the workgroup compacts its misses into LDS (ballot per wave, one LDS add per wave) and its
+// first threads search them -- a few percent of the points in a training loop, i.e. a dozen searches on one wave of a workgroup
+// whose other waves have already left.  No global list, no global atomics on the hot path (one statistics add per workgroup).
+__global__ __launch_bounds__(256) void nn_cache_update_kernel(int P, const float *query, const char *grid, NnCacheView c) {
+  __shared__ uint32_t s_miss[256];
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
   const int p = blockIdx.x * 256 + threadIdx.x;
   bool miss = false;
   if (p < P) {
@@ -288,22 +295,24 @@ __global__ __launch_bounds__(256) void nn_cache_check_kernel(int P, const float 
     miss = !(e.w > 0.f && d2 < e.w * e.w);  // (NaN positions miss, like a negative rho)
   }
   const uint64_t m = __ballot(miss);
-  if (m == 0ull) return;
-  const uint32_t lane = lane_id();
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&c.count[0], (uint32_t)__builtin_popcountll(m));
-  base = __builtin_amdgcn_readfirstlane(base);
-  if (miss) c.miss[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
-}
-__global__ __launch_bounds__(256) void nn_cache_search_kernel(const float *query, const char *grid, NnCacheView c) {
-  const uint32_t n = c.count[0];
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t p = c.miss[i];
-    const float q[3] = {query[3 * (size_t)p], query[3 * (size_t)p + 1], query[3 * (size_t)p + 2]};
+  if (m != 0ull) {
+    const uint32_t lane = lane_id();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&s_n, (uint32_t)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (miss) s_miss[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  if (n == 0u) return;
+  if (threadIdx.x == 0) atomicAdd(&c.count[0], n);  // statistics only
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const uint32_t q_i = s_miss[i];
+    const float q[3] = {query[3 * (size_t)q_i], query[3 * (size_t)q_i + 1], query[3 * (size_t)q_i + 2]};
     float best, other;
     const int id = grid_nearest(grid, q, &best, &other);
-    c.ids[p] = id;
-    c.entry[p] = make_float4(q[0], q[1], q[2], nn_cache_rho(best, other));
+    c.ids[q_i] = id;
+    c.entry[q_i] = make_float4(q[0], q[1], q[2], nn_cache_rho(best, other));
   }
 }
 // (the frame's bookkeeping -- statistics += this frame's misses, counter back to zero for the next frame -- is done by thread 0 of
@@ -808,12 +817,7 @@ int gsr_lbs_forward_cached(int P, int V, const float *query, const float *normal
     a.cache_entry = c.entry, a.cache_ids = c.ids;
     hipLaunchKernelGGL(gsr::lbs_forward_kernel<true>, grid, block, 0, stream, a);
   } else {
-    hipLaunchKernelGGL(gsr::nn_cache_check_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, query, c);
-    // (the misses are a few percent of the points in a training loop: one workgroup per CU strides over them; a launch sized for the
-    // worst case -- every point a miss -- spent 16 us starting 782 workgroups that read one word and left)
-    const int sblocks_full = (P + 255) / 256 < 256 ? (P + 255) / 256 : 256;
-    const int sblocks = getenv("GSR_NN_SBLOCKS") ? atoi(getenv("GSR_NN_SBLOCKS")) : sblocks_full;
-    hipLaunchKernelGGL(gsr::nn_cache_search_kernel, dim3(sblocks), dim3(256), 0, stream, query, workspace, c);
+    hipLaunchKernelGGL(gsr::nn_cache_update_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, query, workspace, c);
     a.given_ids = c.ids, a.cache_count = c.count;
     hipLaunchKernelGGL(gsr::lbs_forward_kernel<true>, grid, block, 0, stream, a);
   }

@@ -4,7 +4,7 @@ tag=$1
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-export PROFILE=1 KEYS=phase1
+export PROFILE=1 KEYS=${KEYS:-phase1}   # KEYS=fused: the phase-1 training loss fused with the rasterizer
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_rstats -- python $root/tools/render_bench.py > $out/${tag}_rstats.log 2>&1
 python - <<PY
 import csv,glob

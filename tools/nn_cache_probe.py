@@ -35,7 +35,34 @@ def timed(n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+def graph_time(n=200):
+    """GPU time of one deform call as a hipGraph replay (no host overhead in the number)."""
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        for _ in range(3):
+            deform()
+    torch.cuda.current_stream().wait_stream(s_)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        deform()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
 with torch.no_grad():
+    for cached in (False, True, False, True):
+        lbs.NN_TEMPORAL_CACHE = cached
+        deform()
+        print(f"cache={cached}: {graph_time():.1f} us of GPU time per coarse_deform_c2source call as a graph replay (static points)", flush=True)
     for cached in (False, True):
         lbs.NN_TEMPORAL_CACHE = cached
         deform()

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 from mygauhuman_amd import cameras  # noqa: E402
 from mygauhuman_amd.gaussian_renderer import render  # noqa: E402
 from mygauhuman_amd.scene_model import HumanGaussianModel  # noqa: E402
@@ -45,14 +46,20 @@ def scene(P=200_000, V=6890, W=1024, H=1024):
 
 def main(P=200_000, V=6890, W=1024, H=1024):
     model, cam, bg = scene(P, V, W, H)
-    for sep, keys in ((False, PHASE1_KEYS if os.environ.get("KEYS") == "phase1" else ALL_KEYS),) if (os.environ.get("PROFILE") or os.environ.get("ONLY")) else (((False, PHASE1_KEYS), (False, ALL_KEYS), (False, PHASE1_KEYS), (False, ALL_KEYS)) if os.environ.get("ORDER") else ((False, ALL_KEYS), (False, PHASE1_KEYS), (True, ALL_KEYS))):
+    for sep, keys in ((False, PHASE1_KEYS if os.environ.get("KEYS") in ("phase1", "fused") else ALL_KEYS),) if (os.environ.get("PROFILE") or os.environ.get("ONLY")) else (((False, PHASE1_KEYS), (False, ALL_KEYS), (False, PHASE1_KEYS), (False, ALL_KEYS)) if os.environ.get("ORDER") else ((False, ALL_KEYS), (False, PHASE1_KEYS), (True, ALL_KEYS))):
         pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True, separate_feature_passes=sep, sync_free_raster=os.environ.get("SYNC_FREE", "1") != "0")
+
+        fused = None
+        if os.environ.get("KEYS") == "fused":   # the phase-1 TRAINING loss of train.py:261-265, fused with the rasterizer (round 4)
+            import bench
+            from mygauhuman_amd.diff_gaussian_rasterization._C import Phase1Loss
+            fused = Phase1Loss(*bench._phase1_targets(W, H, "cuda"))
 
         def step():
             for p in model.parameters():
                 p.grad = None
-            o = render(1, cam, model, pipe, bg)
-            loss = sum(o[k].mean() for k in keys)
+            o = render(1, cam, model, pipe, bg, fused_loss=fused)
+            loss = o["loss"] if fused is not None else sum(o[k].mean() for k in keys)
             loss.backward()
             return o
         for _ in range(30):  # first steps after a change of the loss composition load new torch kernels / grow the allocator
