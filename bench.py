@@ -125,7 +125,7 @@ def pmc_summary(stage, workload):
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))  # r1d < r2a < ...: the newest round last
-    prefix = {"blend_bwd": "blend_backward_kernel<", "blend_fwd": "blend_forward_kernel<"}.get(stage)
+    prefix = {"blend_bwd": ("blend_backward_lds_kernel<", "blend_backward_kernel<"), "blend_fwd": ("blend_forward_kernel<",)}.get(stage)
     if workload != "C3" or not files or prefix is None:
         return None
     for r in csv.DictReader(open(files[-1])):
@@ -133,7 +133,8 @@ def pmc_summary(stage, workload):
             out = {"source": "profiles/" + os.path.basename(files[-1]), "kernel": r["kernel"],
                    "traffic": int(float(r["fetch_bytes_x2"]) + float(r["write_bytes"]))}
             for k_csv, k in (("SQ_INSTS_VALU_per_launch", "valu_insts"), ("SQ_ACTIVE_INST_VALU_per_launch", "active_inst_valu_quads"),
-                             ("SQ_BUSY_CYCLES_per_launch", "sq_busy_cycles"), ("avg_us_under_pmc", "avg_us_under_pmc")):
+                             ("SQ_BUSY_CYCLES_per_launch", "sq_busy_cycles"), ("avg_us_under_pmc", "avg_us_under_pmc"),
+                             ("SQ_LDS_IDX_ACTIVE_per_launch", "lds_idx_active"), ("SQ_LDS_BANK_CONFLICT_per_launch", "lds_bank_conflict")):
                 try:
                     out[k] = float(r[k_csv])
                 except (KeyError, ValueError):
@@ -642,6 +643,12 @@ def main():
                 "cycles_per_inst_per_simd": round(dom_avg_ms * 1e-3 * clock_before * 1e9 * N_SIMD / n_i, 3),
                 "insts_per_walked_instance": round(n_i / max(R_walked, 1), 1),
                 "source": pmc["source"] + " (instruction count: the builder's box; launch time and clock: this run)"}
+            if "lds_idx_active" in pmc:
+                # the unit round 4's census found busiest: LDS-array cycles (SQ_LDS_IDX_ACTIVE, summed over the CUs) / 256 CUs over the
+                # launch's cycles at the measured clock; conflict cycles are part of them
+                roof["lds_array"] = {"busy_cycles_per_launch": int(pmc["lds_idx_active"]), "bank_conflict_cycles": int(pmc.get("lds_bank_conflict", 0)),
+                                     "frac": round(pmc["lds_idx_active"] / 256.0 / (dom_avg_ms * 1e-3 * clock_before * 1e9), 4),
+                                     "source": pmc["source"]}
         out = {
             "metric": "frames/sec fwd+bwd @1024^2, 200k Gaussians" if a.workload == "C3" else f"frames/sec {wl['desc']}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
