@@ -7,6 +7,7 @@ the MI355X HIP library instead of the CUDA extension.
     rasterize_gaussians             (:21-42)    functional form
     _C                              (DGR/ext.cpp:15-19) raw bindings used by baking.py:259-282
 """
+import os
 from typing import NamedTuple
 
 import torch
@@ -51,9 +52,19 @@ def _call_guarded(fn, args, debug, dump_name, phase):
         raise
 
 
+# GaussianRasterizer(...)(...) -- the call train.py / render.py make through gaussian_renderer -- never hands num_rendered to its caller
+# (:215-223 returns colour, radii, depth, alpha), so it does not have to WAIT for it either: with SYNC_FREE (default on; environment
+# GSR_SYNC_FREE_RASTER=0 or this attribute = False restore the reference's blocking read, CR/rasterizer_impl.cu:283) the module call
+# sizes the binning buffer generously (_C.AsyncCapacity), keeps R on the device and examines the overflow flag at the end of the
+# backward / at a later call / for a frame without backward at the end of the call itself: never silently.  The raw binding
+# _C.rasterize_gaussians keeps the reference's return tuple and therefore its blocking read.
+SYNC_FREE = os.environ.get("GSR_SYNC_FREE_RASTER", "1") != "0"
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                sync_free=False, will_backward=True):
         rs = raster_settings
         # the binding's positional order (DGR/rasterize_points.h:19-39)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -63,8 +74,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         # built and measured SLOWER in the render() frame: preprocess forward 9.7 -> 19.2 us and backward 18.2 -> 28.7 us (it then
         # clears the rows it consumed) against one 5 us fill kernel; the wrappers do not use it)
         ctx.rows_zeroed = False
-        num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
-            lambda *x: _C.rasterize_gaussians(*x, rows_zeroed=ctx.rows_zeroed), args, rs.debug, "snapshot_fw.dump", "forward")
+        ctx.watch = None
+        if sync_free:
+            out = _call_guarded(lambda *x: _C.rasterize_gaussians_async(*x, rows_zeroed=ctx.rows_zeroed), args, rs.debug,
+                                "snapshot_fw.dump", "forward")
+            num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer = out[:8]
+            if will_backward:
+                ctx.watch = out[9]   # examined at the end of backward(), before an optimizer can consume the gradients
+            elif out[9] is not None:
+                _C.AsyncCapacity.check(out[9])   # a frame nobody will backpropagate through: raise on THIS call
+        else:
+            num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
+                lambda *x: _C.rasterize_gaussians(*x, rows_zeroed=ctx.rows_zeroed), args, rs.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -76,6 +97,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer,
          alpha) = ctx.saved_tensors
+        if ctx.watch is not None:
+            _C.AsyncCapacity.poll(means3D.device)
         # DGR/rasterize_points.h:41-66
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, grad_alpha, sh,
@@ -83,15 +106,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _call_guarded(lambda *x: _C.rasterize_gaussians_backward(*x, rows_zeroed=ctx.rows_zeroed), args, rs.debug,
                                          "snapshot_bw.dump", "backward")
+        if ctx.watch is not None:   # the whole backward is queued: wait for the FORWARD's overflow flag only
+            _C.AsyncCapacity.check(ctx.watch)
         # gradients in the order of forward()'s inputs (:146-156); raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
-                grad_cov3Ds_precomp, None)
+                grad_cov3Ds_precomp, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, sync_free=None):
+    """sync_free: None = the module default SYNC_FREE."""
+    sync_free = SYNC_FREE if sync_free is None else bool(sync_free)
+    # decided HERE, in the caller's grad mode (inside Function.forward grad mode is always off)
+    will_backward = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                                                  cov3Ds_precomp))
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, sync_free, will_backward)
 
 
 _ZERO_IMAGES = {}

@@ -13,7 +13,7 @@ d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(sys.argv[2], d["value"], d["ms_per_step"], d["step_ms"], {k:round(v,4) for k,v in d["stage_ms"].items()}, "dom", d["roofline"]["avg_launch_ms"], "clk", d["device_clock_ghz_first"], d["device_clock_ghz_measured"], d["device_clock_ghz_after"])
 e=d.get("extra")
 if e:
-    print("  fwd_only", e["forward_only"]["value"], "C2", e["C2"]["value"], "C5", e["C5"]["value"], "dropin", e["dropin_rasterizer_c3"]["ms_per_step"], "render eager/graph", e["render_200k"]["eager"]["ms_per_step"], e["render_200k"]["one_graph"].get("ms_per_step"), "torch-loss graph", e["render_200k"]["torch_loss"]["one_graph"].get("ms_per_step"), "c5 parts", e["c5_lbs_dist2"])
+    print("  fwd_only", e["forward_only"]["value"], "C2", e["C2"]["value"], "C5", e["C5"]["value"], "dropin", e["dropin_rasterizer_c3"]["ms_per_step"], e["dropin_rasterizer_c3"].get("blocking_num_rendered_read", {}).get("ms_per_step"), "render eager/graph", e["render_200k"]["eager"]["ms_per_step"], e["render_200k"]["one_graph"].get("ms_per_step"), "torch-loss graph", e["render_200k"]["torch_loss"]["one_graph"].get("ms_per_step"), "c5 parts", e["c5_lbs_dist2"])
     print("  cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["lbs_project_ms"])
 PY
 done
