@@ -173,9 +173,12 @@ __global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_k
     bool keep = false;
     if (idx < n) keep = (r0.x + r2.z >= rx0) && (r0.x - r2.z <= rx1) && (r0.y + r2.w >= ry0) && (r0.y - r2.w <= ry1);
     float4 r1 = make_float4(0, 0, 0, 0);
-    if (keep) {  // second, exact filter: ellipse {alpha >= 1/255} against the wave's pixel rectangle
+    float l255 = 0.f;
+    if (keep) {  // second, exact filter: ellipse {alpha >= 1/255} against the wave's pixel rectangle (hardware reciprocals, the
+                 // logarithm shared with the survivor row: gsr_common.h ellipse_hits_rect_fast)
       r1 = r1c;
-      keep = ellipse_hits_rect(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rx0, rx1, ry0, ry1);
+      l255 = __builtin_amdgcn_logf(255.0f * r1.y);
+      keep = ellipse_hits_rect_fast(r0.x, r0.y, r0.z, r0.w, r1.x, l255, rx0, rx1, ry0, ry1);
     }
     const uint64_t kmask = __ballot(keep);
     const int cnt = __builtin_popcountll(kmask);
@@ -184,7 +187,7 @@ __global__ __launch_bounds__((WAVE * fwd_wpg<SLOTS, CE>())) void blend_forward_k
       // exponent in base 2: p2 = power * log2(e) = dx (qa dx + qb dy) + qc dy dy
       constexpr float L2E = 1.4426950408889634f;
       s0[slot] = make_float4(r0.x, r0.y, (-0.5f * L2E) * r0.z, -L2E * r0.w);
-      s1[slot] = make_float4((-0.5f * L2E) * r1.x, __builtin_amdgcn_logf(255.0f * r1.y), __uint_as_float((uint32_t)(idx + 1)), r1.y);
+      s1[slot] = make_float4((-0.5f * L2E) * r1.x, l255, __uint_as_float((uint32_t)(idx + 1)), r1.y);
       s2[slot] = make_float4(r1.w, r2.x, r2.y, r1.z);
       if (CE > 0) {
         const float2 *xs = reinterpret_cast<const float2 *>(a.extra + (size_t)id * CE);
