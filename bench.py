@@ -575,26 +575,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- untimed: a pass with every stage bracketed by events to find the dominant kernel (before the warm-up: the stage events
-    # synchronise, and nothing may sit between the warm-up and the timed region)
+    # ---- untimed: bring the GPU to the shader clock it sustains.  A freshly leased MI355X starts at 2.26 GHz and needs ~20 ms of
+    # load to reach 2.39-2.43 (it falls back after 50 ms of idle: tools/clock_ramp.py, profiles/r4_clock_ramp.txt); the driver's
+    # `--steps 20 --warmup 5` is 13 ms of work in all and read 10 % below a 300-step run of the same build on the same box (round 4).
+    # The probe (a dependent FMA chain per SIMD bracketed by s_memtime and the 100 MHz counter) runs until five readings agree.
+    clock_hist = _lib.settle_clock(dev)
+    clock_before = clock_hist[-1][1]
+    # ---- untimed: two passes with every stage bracketed by events to find the dominant kernel (the smaller average per stage: one
+    # stray preemption must not pick the kernel).  They run BETWEEN the clock settle and the warm-up, back to back with it: a pause
+    # of tens of milliseconds between the last work of this kind and the timed region costs 3-4 % (profiles/r4_settle_experiments.txt:
+    # neither a longer clock settle nor memory traffic during it closes that gap, more steps of the workload itself do).
     sc.one_step()
     stage_ms_cold = None
-    for _ in range(2):  # (two passes, the smaller average per stage: one stray preemption must not pick the kernel)
+    for _ in range(2):
         _lib.profile_enable(_lib.PROF_STAGES)
-        for _ in range(4):
+        for _ in range(8):
             sc.one_step()
         torch.cuda.synchronize()
         cur = {k: (ms / n if n else 0.0) for k, (ms, n) in _lib.profile_read().items()}
         stage_ms_cold = cur if stage_ms_cold is None else {k: min(v, stage_ms_cold[k]) for k, v in cur.items()}
     dominant = max(stage_ms_cold, key=stage_ms_cold.get)
     _lib.profile_enable([dominant])  # only the dominant kernel keeps its two event records in the timed region
-    # ---- untimed: bring the GPU to the shader clock it sustains.  A freshly leased MI355X starts at 2.26 GHz and needs ~20 ms of
-    # load to reach 2.39-2.40 (it falls back after 50 ms of idle: tools/clock_ramp.py, profiles/r4_clock_ramp.txt); the driver's
-    # `--steps 20 --warmup 5` is 13 ms of work in all and read 10 % below a 300-step run of the same build on the same box (round 4).
-    # The probe (a dependent FMA chain per SIMD bracketed by s_memtime and the 100 MHz counter) runs until five readings agree,
-    # then the W warm-up steps and the K timed steps follow back to back; the clock is read again right after the timed region.
-    clock_hist = _lib.settle_clock(dev)
-    clock_before = clock_hist[-1][1]
+    # ---- then the W warm-up steps and the K timed steps; the clock is read again right after the timed region
     for _ in range(max(1, a.warmup)):
         sc.one_step()
 

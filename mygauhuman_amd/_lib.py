@@ -215,7 +215,7 @@ def clock_probe(workgroups=1024, fmas=1 << 19, device=None):
     return cyc / (ticks * 10.0), cyc / fmas
 
 
-def settle_clock(device=None, max_ms=1500.0, tol=0.004, probe_fmas=1 << 19):
+def settle_clock(device=None, max_ms=1500.0, tol=0.004, probe_fmas=1 << 19, min_ms=0.0):
     """Run the clock probe back to back until five consecutive readings agree within `tol` (or max_ms have passed): brings a GPU
     that has just been handed to the process to the clock it sustains (2.26 -> 2.39 GHz over ~20 ms of load on MI355X; it falls
     back after ~50 ms of idle).  Returns the list of (ms since start, GHz) readings."""
@@ -226,7 +226,7 @@ def settle_clock(device=None, max_ms=1500.0, tol=0.004, probe_fmas=1 << 19):
         ms = (time.perf_counter() - t0) * 1e3
         hist.append((round(ms, 1), round(ghz, 4)))
         last = [h[1] for h in hist[-5:]]
-        if (len(last) == 5 and max(last) - min(last) <= tol * max(last)) or ms > max_ms:
+        if (ms >= min_ms and len(last) == 5 and max(last) - min(last) <= tol * max(last)) or ms > max_ms:
             return hist
 
 
