@@ -226,7 +226,9 @@ class CompactShExchange:
         self.side, self.ag_group, self._ag_done, self._ag_timing = None, group, None, []
         if self.world > 1:
             self.form = collective_selftest(torch.device(device), group)
-        want_side = (self.world > 1) if side_stream is None else bool(side_stream)
+        # (GSR_EXCHANGE_SIDE_STREAM=0: everything on the compute stream through the one communicator, as in round 3)
+        want_side = ((self.world > 1 and os.environ.get("GSR_EXCHANGE_SIDE_STREAM", "1") != "0") if side_stream is None
+                     else bool(side_stream))
         if want_side and dist.is_available() and dist.is_initialized():
             if torch.device(device).type == "cuda" and not _staged(self.mine, group):
                 self.side = torch.cuda.Stream(device=device)
