@@ -75,6 +75,8 @@ int gsr_get_binning_mode(void);
  *   "bucket_hist" in {0, 1}: tile-bucket counting without global atomics (per-workgroup LDS histograms + a dense prefix table,
  *       default) or with one returning global atomic per instance (also taken for tile grids beyond 8192 tiles);
  *   "bucket_cstride" in {1, 2, 4, 8, 16}: spacing (in 4-byte words) of the per-tile counters of the atomic variant;
+ *   "bucket_sort_merged" in {0, 1}: histogram path -- the sort of the short lists (a wave per tile) and of the long ones (a
+ *       workgroup per list, from a work list) in one launch (default) or in two;
  *   "tile_order" in {0, 1, 2, 3}: the order in which the blend kernels visit the tiles (tile-bucket back-end, histogram path): 1 =
  *       longest list first, dealt round-robin to the XCDs (default), 0 = the natural order (a contiguous band of tile rows per
  *       XCD), 2 / 3 = blocks of 2 x 2 / 4 x 2 tiles by summed length, a block per XCD; results do not depend on it;

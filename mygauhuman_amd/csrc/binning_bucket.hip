@@ -786,17 +786,10 @@ __device__ __forceinline__ void wave_sort_tile_runs(const uint64_t *b, int n, ui
   }
 }
 
-__global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ranges, const uint64_t *bucket, uint32_t *point_list,
-                                                               uint64_t *keys_sorted, uint32_t *big_list, uint32_t *big_count) {
-  __shared__ uint64_t s_runs[MERGE_MAX_RUNS * WAVE];
-  const uint32_t tile = blockIdx.x, lane = threadIdx.x;
-  const uint2 r = ranges[tile];
+// one wave sorts the list of one tile (n <= SORT_WAVE_MAX); s_runs: MERGE_MAX_RUNS x 64 keys of LDS of its own
+__device__ __forceinline__ void wave_sort_any(uint32_t tile, uint32_t lane, const uint2 r, const uint64_t *bucket, uint32_t *point_list,
+                                              uint64_t *keys_sorted, uint64_t *s_runs) {
   const int n = (int)(r.y - r.x);
-  if (n > SORT_WAVE_MAX) {  // left to bucket_sort_kernel: onto its work list unless the scatter kernel already built it (big_list null)
-    if (big_list && lane == 0) big_list[atomicAdd(big_count, 1u)] = tile;
-    return;
-  }
-  if (n == 0) return;
   const uint64_t *b = bucket + r.x;
   if (n <= 64)
     wave_sort_tile<1>(b, n, tile, r.x, point_list, keys_sorted, lane);
@@ -812,6 +805,20 @@ __global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ran
     wave_sort_tile_runs<6>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
   else
     wave_sort_tile_runs<8>(b, n, tile, r.x, point_list, keys_sorted, lane, s_runs);
+}
+
+__global__ __launch_bounds__(WAVE) void bucket_sort_wave_kernel(const uint2 *ranges, const uint64_t *bucket, uint32_t *point_list,
+                                                               uint64_t *keys_sorted, uint32_t *big_list, uint32_t *big_count) {
+  __shared__ uint64_t s_runs[MERGE_MAX_RUNS * WAVE];
+  const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+  const uint2 r = ranges[tile];
+  const int n = (int)(r.y - r.x);
+  if (n > SORT_WAVE_MAX) {  // left to bucket_sort_kernel: onto its work list unless the scatter kernel already built it (big_list null)
+    if (big_list && lane == 0) big_list[atomicAdd(big_count, 1u)] = tile;
+    return;
+  }
+  if (n == 0) return;
+  wave_sort_any(tile, lane, r, bucket, point_list, keys_sorted, s_runs);
 }
 
 // CAP = LDS capacity in keys; handles tiles with LO < n <= CAP in LDS, n > CAP (TAKES_OVERSIZE) as CAP-sized chunks merged in
@@ -971,6 +978,34 @@ __global__ __launch_bounds__(256) void bucket_sort_kernel(const uint2 *ranges, u
   }
 }
 
+// Both sorts in ONE launch (histogram path: the work list of the long lists exists before the launch).  The first n_big workgroups
+// stride over the work list as bucket_sort_kernel does -- first, because in a close-up of a body they are the longest pole (35 us
+// against 17 for the short lists) -- and every other workgroup sorts four tiles, a wave each, as bucket_sort_wave_kernel does
+// (its 4 KB of run buffers per wave lie inside the 32 KB the long-list role needs).  One launch less per frame (the empty long-list
+// launch cost 4.7 us at C3) and the two sorts overlap without a second stream (fork / join by events cost more than it gained).
+template <int CAP, int LO, bool TAKES_OVERSIZE>
+__global__ __launch_bounds__(256) void bucket_sort_both_kernel(const uint2 *ranges, uint64_t *bucket, uint32_t *point_list,
+                                                              uint64_t *keys_sorted, const uint32_t *big_list, const uint32_t *big_count,
+                                                              uint32_t n_big, uint32_t tiles) {
+  __shared__ uint64_t s_keys[2 * CAP];
+  static_assert(2 * CAP >= 4 * MERGE_MAX_RUNS * WAVE, "the four waves' run buffers fit the long-list buffers");
+  if (blockIdx.x < n_big) {
+    const uint32_t count = *big_count;
+    for (uint32_t k = blockIdx.x; k < count; k += n_big) {
+      sort_big_tile<CAP, LO, TAKES_OVERSIZE>(big_list[k], s_keys, ranges, bucket, point_list, keys_sorted);
+      __syncthreads();  // s_keys is reused by the next tile
+    }
+    return;
+  }
+  const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const uint32_t tile = (blockIdx.x - n_big) * 4u + wave;
+  if (tile >= tiles) return;  // (no workgroup barrier in this role: the waves are independent)
+  const uint2 r = ranges[tile];
+  const int n = (int)(r.y - r.x);
+  if (n == 0 || n > SORT_WAVE_MAX) return;
+  wave_sort_any(tile, lane, r, bucket, point_list, keys_sorted, s_keys + wave * (MERGE_MAX_RUNS * WAVE));
+}
+
 // The histogram / scatter workgroups split the P Gaussians EVENLY over a multiple of the CU count (at most HB each, at least one
 // preprocess block): 200k Gaussians on 256 CUs = 256 workgroups of 782 instead of 196 of 1024 with 60 CUs idle.
 static int cu_count() {
@@ -1082,13 +1117,20 @@ int bucket_binning(const GeomState &g, const int *radii, int P, int grid_x, int 
   // (Measured and dropped: the long-list sort on a side stream NEXT TO the wave sort, fork / join by events -- the kernels are
   // independent once the list is built up front.  The two event dependencies cost more than the overlap gains on this runtime: C3
   // binning 61 -> 71..77 us, render() as one graph 0.803 -> 0.836 ms.)
+  const unsigned big_grid = 4u * (unsigned)cu_count();  // SORT_BIG keys = 32 KB of LDS each: up to five per CU
+  const unsigned n_big = (unsigned)(tiles < big_grid ? tiles : big_grid);
+  if (hist && opt.bucket_sort_merged) {  // (the work list is complete: the scatter kernel's order builder wrote it)
+    hipLaunchKernelGGL((bucket_sort_both_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3(n_big + (unsigned)((tiles + 3) / 4)), dim3(256), 0,
+                       stream, ranges, b.keys_a, b.vals_s, b.keys_s, b.tile_cursor, g.total + 2, n_big, (uint32_t)tiles);
+    GSR_LAUNCH_CHECK(stream, debug);
+    return GSR_OK;
+  }
   hipLaunchKernelGGL(bucket_sort_wave_kernel, dim3((unsigned)tiles), dim3(WAVE), 0, stream, ranges, b.keys_a, b.vals_s, b.keys_s,
                      hist ? (uint32_t *)nullptr : b.tile_cursor, g.total + 2);
   GSR_LAUNCH_CHECK(stream, debug);
   // (a separate 16 KB-LDS instantiation for 1025..2048 keys was measured: slower -- the register sorts of the runs, not the
   // LDS occupancy, bound this kernel)
-  const unsigned big_grid = 4u * (unsigned)cu_count();  // SORT_BIG keys = 32 KB of LDS each: up to five per CU
-  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3((unsigned)(tiles < big_grid ? tiles : big_grid)), dim3(256),
+  hipLaunchKernelGGL((bucket_sort_kernel<SORT_BIG, SORT_WAVE_MAX, true>), dim3(n_big), dim3(256),
                      0, stream, ranges, b.keys_a, b.vals_s, b.keys_s, b.tile_cursor, g.total + 2);
   GSR_LAUNCH_CHECK(stream, debug);
   return GSR_OK;

@@ -126,6 +126,9 @@ static int set_option(Options &o, const char *key, int v) {
   } else if (!strcmp(key, "bucket_hist")) {
     if (v != 0 && v != 1) return bad("0 or 1");
     o.bucket_hist = v;
+  } else if (!strcmp(key, "bucket_sort_merged")) {
+    if (v != 0 && v != 1) return bad("0 or 1");
+    o.bucket_sort_merged = v;
   } else if (!strcmp(key, "tile_order")) {
     if (v < 0 || v > 3) return bad("0 (natural order), 1 (longest lists first), 2 / 3 (2 x 2 / 4 x 2 tile blocks by summed length, a block per XCD)");
     o.tile_order = v;

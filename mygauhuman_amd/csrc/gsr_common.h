@@ -237,6 +237,7 @@ struct Options {
   int tile_cull = 1;         // exact ellipse-vs-tile culling of instances in the tile-bucket back-end
   int tile_order = 1;        // blend kernels visit the tiles longest list first, spread over the XCDs (1, default) or in the natural order (0)
   int bucket_hist = 1;       // atomics-free counting of the tile-bucket back-end (LDS histograms per workgroup); 0 = global atomics
+  int bucket_sort_merged = 1;  // histogram path: the per-tile sorts of short and long lists as ONE launch (0: two launches)
   int bucket_cstride = 4;    // counters per 64-byte line = 16 / stride (interleaved A/B at C3, us of binning: 1: 112, 2: 106, 4: 100, 16: 126)
   int blend_fwd_dma = 0;     // 1: fused multi-feature forward with the feature rows staged half a batch ahead by global -> LDS DMA
                              // (parity-green experiment, SLOWER: 191 vs 144 us in the render() frame, profiles/r3_fwd_dma_experiment.txt)
