@@ -509,6 +509,15 @@ int gsr_model_activations_backward(int P, const float *rotation_raw, const float
                                    const float *g_scaling, const float *g_rotation, const float *g_normal,
                                    const float *g_occlusion, float *d_opacity_raw, float *d_albedo_raw, float *d_scaling_raw,
                                    float *d_rotation_raw, float *d_normal_raw, gsr_stream_t stream);
+/* The same with acc_drotation_raw [P][4] (or null) ADDED to d_rotation_raw: a gradient of the raw quaternion that already exists
+ * (render() hands the raw quaternion to the covariance as well, gaussian_renderer/__init__.py:128-131 / scene/gaussian_model.py:35-42:
+ * the leaf would otherwise receive two gradients and autograd an add kernel per frame). */
+int gsr_model_activations_backward_acc(int P, const float *rotation_raw, const float *normal_raw, const float *opacity,
+                                       const float *albedo, const float *scaling, const float *g_opacity, const float *g_albedo,
+                                       const float *g_scaling, const float *g_rotation, const float *g_normal,
+                                       const float *g_occlusion, float *d_opacity_raw, float *d_albedo_raw, float *d_scaling_raw,
+                                       float *d_rotation_raw, float *d_normal_raw, const float *acc_drotation_raw,
+                                       gsr_stream_t stream);
 
 /* Per-frame, per-Gaussian attributes render() derives between the LBS deform and the rasterizer
  * (gaussian_renderer/__init__.py:128-198; scene/gaussian_model.py:35-42,186-190; utils/general_utils.py:64-157;
@@ -562,6 +571,19 @@ int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float
                                         float *dL_dworld_normals, float *dL_dscales, float *dL_drot_cov, float *dL_drot_axis,
                                         float *dL_dalbedo, float *dL_droughness, float *dL_docclusion, float *dL_dshs,
                                         float *dL_dshs_rest, gsr_stream_t stream);
+/* gsr_frame_attributes_backward_split with two accumulations that save autograd an add kernel each in render()'s frame:
+ * acc_dmeans3D [P][3] (or null) -- the rasterizer's dL_dmeans3D of the same frame -- is ADDED to dL_dmeans3D; and
+ * dL_droughness == dL_dalbedo (the same pointer: albedo and roughness are one tensor, scene/gaussian_model.py:197-199) makes the
+ * kernel write their SUM there.  (Both also hold for the function above: it passes acc_dmeans3D = null.) */
+int gsr_frame_attributes_backward_acc(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                      const float *world_normals, const float *scales, float scale_modifier,
+                                      const float *rot_cov, const float *rot_axis, const float *albedo, const float *roughness,
+                                      const float *occlusion, const float *shs, const float *shs_rest, const float *campos,
+                                      const float *viewmatrix, const float *dL_dcov3D, const float *dL_dcolors,
+                                      const float *dL_dfeatures, float *dL_dmeans3D, float *dL_dtransforms,
+                                      float *dL_dworld_normals, float *dL_dscales, float *dL_drot_cov, float *dL_drot_axis,
+                                      float *dL_dalbedo, float *dL_droughness, float *dL_docclusion, float *dL_dshs,
+                                      float *dL_dshs_rest, const float *acc_dmeans3D, gsr_stream_t stream);
 
 #ifdef __cplusplus
 }

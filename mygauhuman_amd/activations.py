@@ -9,6 +9,7 @@ exp, rotation [P,4] = F.normalize, normal [P,3] = x / |x|, occlusion [P,3] = opa
 """
 import torch
 
+from . import gradlink
 from ._lib import check, lib, ptr
 
 
@@ -28,6 +29,11 @@ class _FrameActivations(torch.autograd.Function):
                                                     ptr(normal), ptr(occlusion), torch.cuda.current_stream(dev).cuda_stream),
                   "gsr_model_activations_forward")
         ctx.save_for_backward(raw[3], raw[4], opacity, albedo, scaling)
+        # (gradlink) this backward runs after the attribute kernel's: it can take that kernel's gradient of the RAW quaternion along
+        ctx.link = gradlink.current() if (ctx.needs_input_grad[3] and rotation_raw.is_contiguous()
+                                          and rotation_raw.dtype == f32) else None
+        if ctx.link is not None:
+            ctx.link.act_rot_in_ptr, ctx.link.act_rot_out_ptr = rotation_raw.data_ptr(), rotation.data_ptr()
         return opacity, albedo, scaling, rotation, normal, occlusion
 
     @staticmethod
@@ -39,10 +45,14 @@ class _FrameActivations(torch.autograd.Function):
         gs = [c(g_opacity), c(g_albedo), c(g_scaling), c(g_rotation), c(g_normal), c(g_occlusion)]
         new = lambda *s: torch.empty(s, dtype=f32, device=dev)  # noqa: E731
         d_op, d_al, d_sc, d_ro, d_no = new(P, 1), new(P, 3), new(P, 3), new(P, 4), new(P, 3)
+        acc = None
+        if ctx.link is not None and ctx.link.rot_grad is not None:
+            acc, ctx.link.rot_grad = ctx.link.rot_grad, None
         with torch.cuda.device(dev):
-            check(lib.gsr_model_activations_backward(P, ptr(rotation_raw), ptr(normal_raw), ptr(opacity), ptr(albedo), ptr(scaling),
-                                                     *[ptr(g) for g in gs], ptr(d_op), ptr(d_al), ptr(d_sc), ptr(d_ro), ptr(d_no),
-                                                     torch.cuda.current_stream(dev).cuda_stream), "gsr_model_activations_backward")
+            check(lib.gsr_model_activations_backward_acc(P, ptr(rotation_raw), ptr(normal_raw), ptr(opacity), ptr(albedo),
+                                                         ptr(scaling), *[ptr(g) for g in gs], ptr(d_op), ptr(d_al), ptr(d_sc),
+                                                         ptr(d_ro), ptr(d_no), ptr(acc), torch.cuda.current_stream(dev).cuda_stream),
+                  "gsr_model_activations_backward")
         return d_op, d_al, d_sc, d_ro, d_no
 
 

@@ -12,6 +12,7 @@ import contextlib
 
 import torch
 
+from . import gradlink
 from ._lib import check, lib, ptr
 
 # view-parallel compact SH exchange (parallel.ViewParallelRender): while a sink is installed, the backward of the attribute
@@ -57,6 +58,18 @@ class _FrameAttributes(torch.autograd.Function):
         ctx.save_for_backward(*([t for t in ins if t is not None] + ([rest] if rest is not None else [])
                                 + ([colors] if ctx.sink is not None else [])))
         ctx.meta = (float(scale_modifier), int(sh_degree), M, transforms.shape)
+        # albedo and roughness as ONE tensor (get_roughness reads _albedo): the backward writes the sum of both gradients once
+        ctx.rough_is_albedo = (albedo.data_ptr() == roughness.data_ptr() and albedo.shape == roughness.shape
+                               and albedo.stride() == roughness.stride())
+        # (gradlink) positions: the rasterizer of this frame may park its dL_dmeans3D for this backward to add in-kernel;
+        # raw quaternion: this backward parks its gradient for the activations' backward when rot_axis is their normalised output
+        link = gradlink.current()
+        ctx.link, ctx.park_rot = link, False
+        if link is not None:
+            if ctx.needs_input_grad[0] and means3D.is_contiguous() and means3D.dtype == f32:
+                link.attr_means_ptr = means3D.data_ptr()
+            ctx.park_rot = (link.act_rot_in_ptr is not None and rot_cov.data_ptr() == link.act_rot_in_ptr
+                            and rot_axis.data_ptr() == link.act_rot_out_ptr and ctx.needs_input_grad[4] and ctx.needs_input_grad[5])
         return cov3D, (colors if colors is not None else torch.empty(0, device=dev)), features
 
     @staticmethod
@@ -80,15 +93,22 @@ class _FrameAttributes(torch.autograd.Function):
         d_rest = new(P, rest.shape[1], 3) if (rest is not None and want_sh) else None
         if ctx.sink is not None and g_colors is not None:
             ctx.sink.collect(colors_fwd, g_colors, means3D)
+        if ctx.rough_is_albedo:
+            d_rough = d_alb   # one pointer: the kernel writes the sum; autograd gets it once (and None for the second use)
+        acc_means = None
+        if ctx.link is not None and ctx.link.means_grad is not None:
+            acc_means, ctx.link.means_grad = ctx.link.means_grad, None
         with torch.cuda.device(dev):
-            check(lib.gsr_frame_attributes_backward_split(
+            check(lib.gsr_frame_attributes_backward_acc(
                 P, D, M, ptr(means3D), ptr(transforms), ptr(wn), ptr(scales), mod, ptr(rot_cov), ptr(rot_axis), ptr(albedo),
                 ptr(roughness), ptr(occlusion), ptr(shs), ptr(rest), ptr(campos), ptr(view), ptr(c(g_cov)), ptr(g_colors),
                 ptr(c(g_features)), ptr(d_means), ptr(d_T), ptr(d_wn), ptr(d_scales), ptr(d_rc), ptr(d_ra), ptr(d_alb),
-                ptr(d_rough), ptr(d_occ), ptr(d_shs), ptr(d_rest), torch.cuda.current_stream(dev).cuda_stream),
+                ptr(d_rough), ptr(d_occ), ptr(d_shs), ptr(d_rest), ptr(acc_means), torch.cuda.current_stream(dev).cuda_stream),
                 "gsr_frame_attributes_backward")
-        return (d_means, d_T.view(t_shape), d_wn, d_scales, d_rc, d_ra, d_alb, d_rough, d_occ, d_shs, None, None, None, None,
-                d_rest)
+        if ctx.park_rot:
+            ctx.link.rot_grad, d_rc = d_rc, None
+        return (d_means, d_T.view(t_shape), d_wn, d_scales, d_rc, d_ra, d_alb, None if ctx.rough_is_albedo else d_rough, d_occ, d_shs,
+                None, None, None, None, d_rest)
 
 
 def frame_attributes(means3D, transforms, world_normals, scales, scale_modifier, rot_cov, rot_axis, albedo, roughness, occlusion,

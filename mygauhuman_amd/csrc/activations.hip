@@ -18,6 +18,7 @@ struct ActArgs {
   // backward: incoming / outgoing gradients
   const float *g_opacity, *g_albedo, *g_scaling, *g_rotation, *g_normal, *g_occlusion;
   float *d_opacity_raw, *d_albedo_raw, *d_scaling_raw, *d_rotation_raw, *d_normal_raw;
+  const float *acc_rotation_raw;  // backward, optional: a gradient of the RAW rotation that already exists, added to d_rotation_raw
 };
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void activations_backward_kernel(const ActArgs
   }
   unit_backward<4>(x, g, 1e-12f, d);
 #pragma unroll
-  for (int k = 0; k < 4; k++) a.d_rotation_raw[4 * (size_t)i + k] = d[k];
+  for (int k = 0; k < 4; k++) a.d_rotation_raw[4 * (size_t)i + k] = d[k] + (a.acc_rotation_raw ? a.acc_rotation_raw[4 * (size_t)i + k] : 0.f);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     x[k] = a.normal_raw[3 * (size_t)i + k];
@@ -129,12 +130,12 @@ extern "C" int gsr_model_activations_forward(int P, const float *opacity_raw, co
   return check_hip(hipGetLastError(), "activations_forward_kernel", __FILE__, __LINE__);
 }
 
-extern "C" int gsr_model_activations_backward(int P, const float *rotation_raw, const float *normal_raw, const float *opacity,
+extern "C" int gsr_model_activations_backward_acc(int P, const float *rotation_raw, const float *normal_raw, const float *opacity,
                                               const float *albedo, const float *scaling, const float *g_opacity,
                                               const float *g_albedo, const float *g_scaling, const float *g_rotation,
                                               const float *g_normal, const float *g_occlusion, float *d_opacity_raw,
                                               float *d_albedo_raw, float *d_scaling_raw, float *d_rotation_raw,
-                                              float *d_normal_raw, gsr_stream_t stream_) {
+                                              float *d_normal_raw, const float *acc_drotation_raw, gsr_stream_t stream_) {
   using namespace gsr;
   if (P < 0 || (P > 0 && (!rotation_raw || !normal_raw || !opacity || !albedo || !scaling || !d_opacity_raw || !d_albedo_raw ||
                           !d_scaling_raw || !d_rotation_raw || !d_normal_raw))) {
@@ -150,7 +151,19 @@ extern "C" int gsr_model_activations_backward(int P, const float *rotation_raw, 
   a.g_occlusion = g_occlusion;
   a.d_opacity_raw = d_opacity_raw, a.d_albedo_raw = d_albedo_raw, a.d_scaling_raw = d_scaling_raw;
   a.d_rotation_raw = d_rotation_raw, a.d_normal_raw = d_normal_raw;
+  a.acc_rotation_raw = acc_drotation_raw;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   hipLaunchKernelGGL(activations_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "activations_backward_kernel", __FILE__, __LINE__);
+}
+
+extern "C" int gsr_model_activations_backward(int P, const float *rotation_raw, const float *normal_raw, const float *opacity,
+                                              const float *albedo, const float *scaling, const float *g_opacity,
+                                              const float *g_albedo, const float *g_scaling, const float *g_rotation,
+                                              const float *g_normal, const float *g_occlusion, float *d_opacity_raw,
+                                              float *d_albedo_raw, float *d_scaling_raw, float *d_rotation_raw,
+                                              float *d_normal_raw, gsr_stream_t stream_) {
+  return gsr_model_activations_backward_acc(P, rotation_raw, normal_raw, opacity, albedo, scaling, g_opacity, g_albedo, g_scaling,
+                                            g_rotation, g_normal, g_occlusion, d_opacity_raw, d_albedo_raw, d_scaling_raw,
+                                            d_rotation_raw, d_normal_raw, nullptr, stream_);
 }

@@ -30,6 +30,7 @@ struct AttrArgs {
   const float *g_cov3D, *g_colors, *g_features;
   float *d_means, *d_transforms, *d_world_normals, *d_scales, *d_rot_cov, *d_rot_axis, *d_albedo, *d_roughness, *d_occlusion,
       *d_shs, *d_shs_rest;
+  const float *acc_means;  // backward, optional: a position gradient that already exists (the rasterizer's dL_dmeans3D) ADDED to d_means
 };
 
 constexpr int ATTR_BLOCK = 256;
@@ -306,13 +307,18 @@ __device__ __forceinline__ void attributes_backward_one(const AttrArgs &a, int i
     for (int k = 0; k < 3; k++) a.d_world_normals[(size_t)i * 3 + k] = dwn_raw[k];
   }
 #pragma unroll
-  for (int k = 0; k < 3; k++) a.d_albedo[(size_t)i * 3 + k] = g[6 + k];
-#pragma unroll
   for (int k = 0; k < 3; k++) a.d_occlusion[(size_t)i * 3 + k] = g[9 + k];
   {
     const float gr = (g[12] + g[13] + g[14]) / 3.0f;
+    if (a.d_roughness == a.d_albedo) {  // (kernel-uniform) albedo and roughness are ONE tensor (get_roughness reads _albedo): one sum
 #pragma unroll
-    for (int k = 0; k < 3; k++) a.d_roughness[(size_t)i * 3 + k] = gr;
+      for (int k = 0; k < 3; k++) a.d_albedo[(size_t)i * 3 + k] = g[6 + k] + gr;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) a.d_albedo[(size_t)i * 3 + k] = g[6 + k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) a.d_roughness[(size_t)i * 3 + k] = gr;
+    }
   }
   {
     AxisChain c;
@@ -348,7 +354,7 @@ __device__ __forceinline__ void attributes_backward_one(const AttrArgs &a, int i
 #pragma unroll
   for (int k = 0; k < 3; k++) a.d_scales[(size_t)i * 3 + k] = dscale[k];
 #pragma unroll
-  for (int k = 0; k < 3; k++) a.d_means[(size_t)i * 3 + k] = dmean[k];
+  for (int k = 0; k < 3; k++) a.d_means[(size_t)i * 3 + k] = dmean[k] + (a.acc_means ? a.acc_means[(size_t)i * 3 + k] : 0.f);
 }
 
 // STAGE: the workgroup's SH block (256 rows x 192 B, contiguous) goes through LDS with coalesced 16-byte accesses; the
@@ -536,14 +542,15 @@ int gsr_frame_attributes_backward(int P, int sh_degree, int M, const float *mean
                                              stream_);
 }
 
-int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+int gsr_frame_attributes_backward_acc(int P, int sh_degree, int M, const float *means3D, const float *transforms,
                                         const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
                                         const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
                                         const float *shs, const float *shs_rest, const float *campos, const float *viewmatrix,
                                         const float *dL_dcov3D, const float *dL_dcolors, const float *dL_dfeatures,
                                         float *dL_dmeans3D, float *dL_dtransforms, float *dL_dworld_normals, float *dL_dscales,
                                         float *dL_drot_cov, float *dL_drot_axis, float *dL_dalbedo, float *dL_droughness,
-                                        float *dL_docclusion, float *dL_dshs, float *dL_dshs_rest, gsr_stream_t stream_) {
+                                        float *dL_docclusion, float *dL_dshs, float *dL_dshs_rest, const float *acc_dmeans3D,
+                                        gsr_stream_t stream_) {
   using namespace gsr;
   if (split_ok("gsr_frame_attributes_backward_split", M, shs, shs_rest, dL_dshs, dL_dshs_rest, true) != GSR_OK) return GSR_EINVAL;
   int rc = check_common("gsr_frame_attributes_backward", P, sh_degree, M, means3D, transforms, world_normals, scales, rot_cov,
@@ -570,6 +577,7 @@ int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float
   a.d_means = dL_dmeans3D, a.d_transforms = dL_dtransforms, a.d_world_normals = dL_dworld_normals, a.d_scales = dL_dscales;
   a.d_rot_cov = dL_drot_cov, a.d_rot_axis = dL_drot_axis, a.d_albedo = dL_dalbedo, a.d_roughness = dL_droughness;
   a.d_occlusion = dL_docclusion, a.d_shs = dL_dshs, a.d_shs_rest = dL_dshs_rest;
+  a.acc_means = acc_dmeans3D;
   const bool stage = shs && M == ASH_M &&
                      (shs_rest || (reinterpret_cast<size_t>(shs) % 16 == 0 && reinterpret_cast<size_t>(dL_dshs) % 16 == 0));  // (null is aligned)
   const dim3 grid((P + ATTR_BLOCK - 1) / ATTR_BLOCK), block(ATTR_BLOCK);
@@ -579,6 +587,20 @@ int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float
     hipLaunchKernelGGL((attributes_kernel<false, true>), grid, block, 0, stream, a);
   GSR_LAUNCH_CHECK(stream, 0);
   return GSR_OK;
+}
+
+int gsr_frame_attributes_backward_split(int P, int sh_degree, int M, const float *means3D, const float *transforms,
+                                        const float *world_normals, const float *scales, float scale_modifier, const float *rot_cov,
+                                        const float *rot_axis, const float *albedo, const float *roughness, const float *occlusion,
+                                        const float *shs, const float *shs_rest, const float *campos, const float *viewmatrix,
+                                        const float *dL_dcov3D, const float *dL_dcolors, const float *dL_dfeatures,
+                                        float *dL_dmeans3D, float *dL_dtransforms, float *dL_dworld_normals, float *dL_dscales,
+                                        float *dL_drot_cov, float *dL_drot_axis, float *dL_dalbedo, float *dL_droughness,
+                                        float *dL_docclusion, float *dL_dshs, float *dL_dshs_rest, gsr_stream_t stream_) {
+  return gsr_frame_attributes_backward_acc(P, sh_degree, M, means3D, transforms, world_normals, scales, scale_modifier, rot_cov, rot_axis,
+                                           albedo, roughness, occlusion, shs, shs_rest, campos, viewmatrix, dL_dcov3D, dL_dcolors,
+                                           dL_dfeatures, dL_dmeans3D, dL_dtransforms, dL_dworld_normals, dL_dscales, dL_drot_cov,
+                                           dL_drot_axis, dL_dalbedo, dL_droughness, dL_docclusion, dL_dshs, dL_dshs_rest, nullptr, stream_);
 }
 
 }  // extern "C"

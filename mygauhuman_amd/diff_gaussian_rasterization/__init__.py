@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from .. import gradlink
 from .._lib import N_EXTRA
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_multi"]
@@ -167,6 +168,11 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
         ctx.rows_zeroed = False
         num_rendered, color, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer, out_extra = out
         ctx.set_materialize_grads(False)  # untouched images arrive as None in backward, not as zero tensors
+        # (gradlink) render(): the attribute kernel of this frame consumes the same positions and its backward runs after this one
+        # (it waits for dL_dextra): the position gradient is parked for it to add in-kernel instead of autograd adding the two
+        link = gradlink.current()
+        ctx.park_means = link if (link is not None and link.attr_means_ptr is not None and link.attr_means_ptr == means3D.data_ptr()
+                                  and ctx.needs_input_grad[0] and ctx.needs_input_grad[4]) else None
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         # fused phase-1 training loss (_C.Phase1Loss): its value is one more output; the backward forms its image gradients in-kernel
@@ -209,6 +215,8 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             # the whole backward is queued; wait for the FORWARD's overflow flag only (the GPU stays busy with the backward)
             # so that an overflow raises before the optimizer consumes these gradients
             _C.AsyncCapacity.check(ctx.watch)
+        if ctx.park_means is not None:
+            ctx.park_means.means_grad, grad_means3D = grad_means3D, None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_extra_in, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, None, None, None, None)
 

@@ -20,9 +20,11 @@ camera_center, smpl_param, big_pose_smpl_param, big_pose_world_vertex (scene/cam
 iterations is used (:141).
 """
 import math
+import os
 
 import torch
 
+from .. import gradlink
 from .. import lbs as _lbs
 from ..attributes import frame_attributes
 from ..covariance import bmm3
@@ -70,12 +72,24 @@ def _features_of(pc):
     return pc.get_features
 
 
+# (gradlink.py) the position / quaternion gradients of a frame meet inside the attribute / activation kernels instead of in three
+# accumulation kernels of autograd; GSR_GRAD_LINK=0 keeps autograd's own accumulation
+GRAD_LINK = os.environ.get("GSR_GRAD_LINK", "1") != "0"
+
+
 def render(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None,
            return_smpl_rot=False, transforms=None, translation=None, envmap=None, fused_loss=None):
     """Render the scene. Background tensor (bg_color) must be on the GPU.
     fused_loss (extension, default None = the reference's behaviour): a diff_gaussian_rasterization._C.Phase1Loss -- the loss
     train.py:261-265 forms from this result (bound-masked L1 on image / normal / axis, 0.1 L2 on alpha) evaluated FUSED with the
     rasterizer: the result then carries "loss" (a 0-dim tensor; add the other terms to it and call backward())."""
+    with gradlink.frame_link(GRAD_LINK and not getattr(pipe, "separate_feature_passes", False)):
+        return _render_frame(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, return_smpl_rot,
+                             transforms, translation, envmap, fused_loss)
+
+
+def _render_frame(iteration, viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, return_smpl_rot, transforms,
+                  translation, envmap, fused_loss):
     dev = pc.get_xyz.device
     # the gradient holder of the 2D means (:62-66: `zeros_like(...) + 0` and retain_grad()): a zero LEAF that requires grad
     # receives the same .grad without the extra add kernel

@@ -331,6 +331,41 @@ def test_render_with_fused_activations_equals_property_getters(oracle):
         util.assert_close("render grads", ga, gb, tol=1e-4, max_bad_frac=2e-4)
 
 
+def test_gradients_joined_in_kernel_equal_autograd_accumulation(oracle, monkeypatch):
+    """mygauhuman_amd.gradlink: the rasterizer parks its position gradient for the attribute kernel's backward, that one parks the
+    raw-quaternion gradient for the activations' backward, and albedo == roughness gets one summed gradient -- three add kernels of
+    autograd less per frame.  a + b in a kernel or in autograd is the same fp32 sum: every parameter gradient equals that of the
+    frame rendered with GSR_GRAD_LINK off to the run-to-run noise of the blend backward's float atomics (1e-5 of the tensor's
+    scale; measured 7e-7), and nothing stays parked."""
+    import mygauhuman_amd.gaussian_renderer as gr
+    from mygauhuman_amd import gradlink
+    grads, links = {}, []
+    real = gradlink.FrameLink
+
+    class Spy(real):
+        __slots__ = ()
+
+        def __init__(self):
+            super().__init__()
+            links.append(self)
+    monkeypatch.setattr(gradlink, "FrameLink", Spy)
+    for on in (False, True):
+        monkeypatch.setattr(gr, "GRAD_LINK", on)
+        s = _human_scene(oracle, seed=7)
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+        o = gr.render(1, s.cam, s.model, pipe, util.to_dev(np.array([0.1, 0.2, 0.3], np.float32)))
+        keys = ("render", "normal", "albedo", "occlusion", "roughness", "world_normal", "render_axis", "render_alpha")
+        sum(o[k].mean() * (i + 1) for i, k in enumerate(keys)).backward()
+        grads[on] = [None if p.grad is None else p.grad.cpu().numpy() for p in s.model.parameters()]
+    assert len(links) == 1 and links[0].attr_means_ptr is not None and links[0].act_rot_in_ptr is not None   # the linked frame
+    assert links[0].means_grad is None and links[0].rot_grad is None                                          # nothing left parked
+    for ga, gb in zip(grads[False], grads[True]):
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            assert np.isfinite(gb).all() and np.abs(gb).max() > 0
+            util.assert_close("gradient joined in kernel", gb, ga, tol=1e-5, max_bad_frac=0.0)
+
+
 def _chain64(s, leaf, ids, dec=None):
     """The reference's per-frame chain from the model's leaf parameters to the rasterizer's inputs, in float64 torch on the CPU
     (scene/gaussian_model.py:157-199 activations, :768-872 LBS with the nearest-vertex ids given, :35-42 covariance,
