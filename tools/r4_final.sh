@@ -3,7 +3,7 @@
 tag=${1:-r4b}
 set -o pipefail
 bash tools/profile_round.sh $tag > gpurun_out/${tag}_profile.log 2>&1; cat gpurun_out/${tag}_profile.log
-KEYS=phase1 bash tools/kstats_render.sh ${tag}_render > gpurun_out/${tag}_render_kernels.txt 2>&1; head -5 gpurun_out/${tag}_render_kernels.txt
+KEYS=fused bash tools/kstats_render.sh ${tag}_render > gpurun_out/${tag}_render_kernels_fused_loss.txt 2>&1; head -5 gpurun_out/${tag}_render_kernels_fused_loss.txt
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_cmd.json 2> gpurun_out/${tag}_bench_driver_cmd.err; echo "driver cmd rc=$?"
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra --no-cpu-baseline > gpurun_out/${tag}_bench_driver_cmd2.json 2>/dev/null
 python bench.py > gpurun_out/${tag}_bench_c3.json 2> gpurun_out/${tag}_bench_c3.err; echo "default rc=$?"
