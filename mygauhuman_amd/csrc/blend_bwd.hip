@@ -1194,6 +1194,9 @@ constexpr int FX_TRI2 = 4 * 3 * 16 + 4;  // floats of one colour triple's second
 #ifndef FX_FULL_ROWS
 #define FX_FULL_ROWS false
 #endif
+#ifndef FX_SPLIT_DOT
+#define FX_SPLIT_DOT true
+#endif
 
 // NL = how many of the six channel triples carry a gradient (popcount of the image mask).  Everything per-channel is sized by it:
 // the survivor rows in LDS hold the LIVE triples only (gathered as such: 12 bytes per live triple instead of the 72-byte row), and so
@@ -1419,9 +1422,23 @@ __device__ __forceinline__ void blend_backward_features_body(const BlendBwdArgs 
             const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
             const float Tn = T * rc;  // transmittance in front of this Gaussian
             const float w = alpha * Tn;  // blending weight = d(pixel)/d(colour)
+            // the dot product over the live channels in three independent partial sums: as ONE chain it is 5 + CL dependent FMAs
+            // (23 with all six triples live, ~9 cycles each for a wave on its own) in front of dL_dalpha
             float e = r.g2.x * dpix0 + r.g2.y * dpix1 + r.g2.z * dpix2 + r.g2.w * ddep + dalp;
+            if constexpr (FX_SPLIT_DOT && CL >= 6) {
+              float ea = 0.f, eb = 0.f;
 #pragma unroll
-            for (int c = 0; c < CL; c++) e += (c % 2 == 0 ? r.x[c / 2].x : r.x[c / 2].y) * dxp[c];
+              for (int c = 0; c < CL; c++) {
+                const float xv = (c % 2 == 0 ? r.x[c / 2].x : r.x[c / 2].y);
+                if (c % 3 == 0) e = __builtin_fmaf(xv, dxp[c], e);
+                else if (c % 3 == 1) ea = __builtin_fmaf(xv, dxp[c], ea);
+                else eb = __builtin_fmaf(xv, dxp[c], eb);
+              }
+              e += ea + eb;
+            } else {
+#pragma unroll
+              for (int c = 0; c < CL; c++) e += (c % 2 == 0 ? r.x[c / 2].x : r.x[c / 2].y) * dxp[c];
+            }
             const float dL_dalpha = Tn * e - (X + Tb) * rc;
             X += w * e;
             T = Tn;
