@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: a record of how profiles/r4_group_fetch_experiment.txt was measured.  It needs the experiment patch of that commit's parent
+# work tree (blend_bwd_reduce = 5 / 6 selected the per-survivor / one-block forms); the tree no longer accepts those knob values.
 # round 4: the plain backward with a group's four survivors fetched together -- parity (default = branchy form, then the one-block
 # form through GSR_TEST_TUNING), then same-box A/B of blend_bwd_reduce = 5 (per-survivor form) / 3 (default) / 6 (one block),
 # and the render() frame old tree vs new (five-wave 18-channel forward)
