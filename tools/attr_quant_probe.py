@@ -1,5 +1,11 @@
 """Is the attribute kernel pair (csrc/attributes.hip) quantised by resident workgroups?  Times forward and backward over P around
-768 x 256 = 196,608 (three 53 KB workgroups per CU x 256 CUs).   python tools/attr_quant_probe.py"""
+768 x 256 = 196,608 (three 53 KB workgroups per CU x 256 CUs).   python tools/attr_quant_probe.py
+
+Measured (round 4, buffers cache-hot): forward 18.7 us at P = 196,608 (768 workgroups, one round), 24.3 at 200,000 (782: a second
+round of 14); backward 26.2 / 34.3.  Tried against it, all slower or equal at 200k: 64-thread workgroups (23.7: the LDS granule
+then admits 11, not 12, per CU), SH rows staged half a row at a time to fit five workgroups per CU -- second half re-read (26.8)
+or held in registers (25.1; 22.1 vs 16.8 at 150k: the extra barrier pair and element-wise LDS writes cost more than the second
+round), the direct (non-staged) instantiation (37.8 / 63.0).  The backward is held to 768 threads per CU by its 168 VGPRs."""
 import os
 import sys
 
