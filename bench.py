@@ -339,7 +339,7 @@ def render_extra(dev, steps=40, warmup=30):
         _phase1_loss_torch(o, *targets).backward()
         return o["render"]
 
-    def measure(step):
+    def measure(step, params):
         def eager():
             for p in params:
                 p.grad = None
@@ -360,10 +360,24 @@ def render_extra(dev, steps=40, warmup=30):
             res["one_graph"] = {"error": str(ex)[:300]}
         return res
     out = {"workload": wl["desc"]}
-    out.update(measure(step_fused))
+    out.update(measure(step_fused, params))
     out["loss"] = ("phase-1 training loss of train.py:261-265 fused with the rasterizer (gsr_phase1_loss_forward + the blend backward's "
                    "prologue): `eager` / `one_graph`; the same loss in torch ops: `torch_loss`")
-    out["torch_loss"] = measure(step_torch)
+    out["torch_loss"] = measure(step_torch, params)
+    # ---- one more figure: the same fused-loss step with motion_offset_flag on and a per-Gaussian skinning-offset
+    # network of the REFERENCE'S SIZE in the frame (human_synth.LbsOffsetMLP: 63-d embedding, 63-128-128-128-(191)-128-24, plain
+    # torch GEMMs; gaussian_renderer/__init__.py:100-106 runs the reference's own every frame) + the pose MLP stand-in
+    model_m, _ = human_synth.build(wl["P"], wl["V"], dev, seed=0, motion=True, decoder="reference_size")
+    params_m = list(model_m.parameters()) + list(model_m.pose_decoder.parameters()) + list(model_m.lweight_offset_decoder.parameters())
+
+    def step_motion():
+        o = render(1, cam, model_m, pipe, bg, fused_loss=spec)
+        o["loss"].backward()
+        return o["render"]
+    out["with_reference_sized_decoder"] = measure(step_motion, params_m)
+    out["with_reference_sized_decoder"]["what"] = (
+        "motion_offset_flag on: pose MLP stand-in + a skinning-offset network of the reference's layer sizes (random init, row-major "
+        "linear layers in torch), fused phase-1 loss; `eager` / `one_graph` above have the decoders off")
     return out
 
 
