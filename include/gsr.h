@@ -585,6 +585,17 @@ int gsr_frame_attributes_backward_acc(int P, int sh_degree, int M, const float *
                                       float *dL_dalbedo, float *dL_droughness, float *dL_docclusion, float *dL_dshs,
                                       float *dL_dshs_rest, const float *acc_dmeans3D, gsr_stream_t stream);
 
+/* The per-Gaussian skinning-weight offset network of render() (nets/mlp_delta_weight_lbs.py:5-32: a 63-d positional embedding of
+ * the canonical position through 63-128-128-128-(63+128)-128-24 with ReLU; gaussian_renderer/__init__.py:100-106 runs it every frame
+ * when motion_offset_flag is set), FORWARD, as one kernel on the matrix cores (csrc/mlp.hip: f32 MFMA, activations in registers).
+ *   gsr_lbs_offset_mlp_pack: weights[5] / biases[5] = the module's tensors in its own layout -- bw_linears.0..3 ([128][63],
+ *     [128][128], [128][128], [128][191]: Conv1d weight [out][in][1]) and bw_fc ([24][128]), biases [128] x 4 and [24] -- host arrays
+ *     of DEVICE pointers; packed: gsr_lbs_offset_mlp_packed_floats() floats, 16-byte aligned (re-pack after every parameter update);
+ *   gsr_lbs_offset_mlp_forward: xyz [P][3] -> out [P][24] (the module returns [1][24][P]: the transposed view of this). */
+size_t gsr_lbs_offset_mlp_packed_floats(void);
+int gsr_lbs_offset_mlp_pack(const float *const *weights, const float *const *biases, float *packed, gsr_stream_t stream);
+int gsr_lbs_offset_mlp_forward(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ SOURCES = [
     ("gemv.hip", []),
     ("loss.hip", []),
     ("probe.hip", []),
+    ("mlp.hip", []),
     ("gsr_api.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

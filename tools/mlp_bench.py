@@ -1,0 +1,26 @@
+"""The skinning-weight offset network at 200k points: fused forward (csrc/mlp.hip) vs the same module in torch ops, no_grad.
+python tools/mlp_bench.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mygauhuman_amd.nets import FusedLBSOffsetDecoder  # noqa: E402
+
+dec = FusedLBSOffsetDecoder().cuda()
+for P in (50_000, 200_000, 500_000):
+    pts = torch.rand(1, P, 3, device="cuda") - 0.5
+    with torch.no_grad():
+        for name, fn in (("fused", lambda: dec(pts)), ("torch ops", lambda: dec.forward_torch(pts))):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 20
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            print(f"P={P:7d} {name:10s} {dt * 1e3:8.3f} ms   {137e3 * P / dt / 1e12:6.1f} TFLOP/s", flush=True)
