@@ -364,20 +364,25 @@ def render_extra(dev, steps=40, warmup=30):
     out["loss"] = ("phase-1 training loss of train.py:261-265 fused with the rasterizer (gsr_phase1_loss_forward + the blend backward's "
                    "prologue): `eager` / `one_graph`; the same loss in torch ops: `torch_loss`")
     out["torch_loss"] = measure(step_torch, params)
-    # ---- one more figure: the same fused-loss step with motion_offset_flag on and a per-Gaussian skinning-offset
-    # network of the REFERENCE'S SIZE in the frame (human_synth.LbsOffsetMLP: 63-d embedding, 63-128-128-128-(191)-128-24, plain
-    # torch GEMMs; gaussian_renderer/__init__.py:100-106 runs the reference's own every frame) + the pose MLP stand-in
-    model_m, _ = human_synth.build(wl["P"], wl["V"], dev, seed=0, motion=True, decoder="reference_size")
-    params_m = list(model_m.parameters()) + list(model_m.pose_decoder.parameters()) + list(model_m.lweight_offset_decoder.parameters())
+    # ---- two more figures: the same fused-loss step with motion_offset_flag on and a per-Gaussian skinning-offset network
+    # of the REFERENCE'S layers in the frame (nets.FusedLBSOffsetDecoder: 63-d embedding, 63-128-128-128-(191)-128-24, random init;
+    # gaussian_renderer/__init__.py:100-106 runs the reference's own every frame) + the pose MLP stand-in: the network on the fused
+    # f32-MFMA kernels of csrc/mlp.hip, and the same module in torch ops
+    for key, dec in (("with_reference_sized_decoder", "reference_size"), ("with_reference_sized_decoder_in_torch_ops", "reference_size_torch")):
+        model_m, _ = human_synth.build(wl["P"], wl["V"], dev, seed=0, motion=True, decoder=dec)
+        params_m = (list(model_m.parameters()) + list(model_m.pose_decoder.parameters())
+                    + list(model_m.lweight_offset_decoder.parameters()))
 
-    def step_motion():
-        o = render(1, cam, model_m, pipe, bg, fused_loss=spec)
-        o["loss"].backward()
-        return o["render"]
-    out["with_reference_sized_decoder"] = measure(step_motion, params_m)
+        def step_motion(model_m=model_m):
+            o = render(1, cam, model_m, pipe, bg, fused_loss=spec)
+            o["loss"].backward()
+            return o["render"]
+        out[key] = measure(step_motion, params_m)
+        del model_m, params_m
     out["with_reference_sized_decoder"]["what"] = (
-        "motion_offset_flag on: pose MLP stand-in + a skinning-offset network of the reference's layer sizes (random init, row-major "
-        "linear layers in torch), fused phase-1 loss; `eager` / `one_graph` above have the decoders off")
+        "motion_offset_flag on: pose MLP stand-in + a skinning-offset network of the reference's layers (random init), fused phase-1 "
+        "loss; the network forward + backward on the f32-MFMA kernels of csrc/mlp.hip (`with_reference_sized_decoder`) or in torch ops "
+        "(`..._in_torch_ops`); `eager` / `one_graph` above have the decoders off")
     return out
 
 

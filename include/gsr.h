@@ -587,7 +587,7 @@ int gsr_frame_attributes_backward_acc(int P, int sh_degree, int M, const float *
 
 /* The per-Gaussian skinning-weight offset network of render() (nets/mlp_delta_weight_lbs.py:5-32: a 63-d positional embedding of
  * the canonical position through 63-128-128-128-(63+128)-128-24 with ReLU; gaussian_renderer/__init__.py:100-106 runs it every frame
- * when motion_offset_flag is set), FORWARD, as one kernel on the matrix cores (csrc/mlp.hip: f32 MFMA, activations in registers).
+ * when motion_offset_flag is set) on the matrix cores (csrc/mlp.hip: f32 MFMA, activations in registers): forward = one kernel.
  *   gsr_lbs_offset_mlp_pack: weights[5] / biases[5] = the module's tensors in its own layout -- bw_linears.0..3 ([128][63],
  *     [128][128], [128][128], [128][191]: Conv1d weight [out][in][1]) and bw_fc ([24][128]), biases [128] x 4 and [24] -- host arrays
  *     of DEVICE pointers; packed: gsr_lbs_offset_mlp_packed_floats() floats, 16-byte aligned (re-pack after every parameter update);
@@ -595,6 +595,13 @@ int gsr_frame_attributes_backward_acc(int P, int sh_degree, int M, const float *
 size_t gsr_lbs_offset_mlp_packed_floats(void);
 int gsr_lbs_offset_mlp_pack(const float *const *weights, const float *const *biases, float *packed, gsr_stream_t stream);
 int gsr_lbs_offset_mlp_forward(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream);
+/* Backward w.r.t. the parameters (the positions arrive detached, gaussian_renderer/__init__.py:104: no input gradient).  The forward
+ * is run again inside (no activation was kept), dL_dout is [P][24]; the gradients are ADDED into dL_dweights[5] / dL_dbiases[5] (host
+ * arrays of device pointers, the module's own layouts: zero them first); workspace: gsr_lbs_offset_mlp_backward_workspace_floats(P)
+ * floats, 16-byte aligned (every layer's activations and pre-activation gradients, feature-major, for the weight-gradient products). */
+size_t gsr_lbs_offset_mlp_backward_workspace_floats(int P);
+int gsr_lbs_offset_mlp_backward(int P, const float *xyz, const float *packed, const float *dL_dout, float *workspace,
+                                float *const *dL_dweights, float *const *dL_dbiases, gsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 //     of the current layer sit in LDS (<= 96 KB), one ds_read_b128 per k-step feeds the four output tiles.
 // Arithmetic: 137 kFLOP per point = 27 GFLOP at 200k points = 16,384 MFMA cycles per 128 x 128 layer per wave.
 #include <math.h>
+#include <string.h>
 
 #include "gsr_common.h"
 
@@ -38,6 +39,16 @@ constexpr int MLP_PACKED_W = mlp_packed_offset(MLP_LAYERS);     // floats of all
 constexpr int MLP_PACKED_B = 4 * MLP_W + 32;                      // biases, the last layer padded to 32
 constexpr int MLP_PACKED = MLP_PACKED_W + MLP_PACKED_B;
 constexpr int MLP_LDS_FLOATS = mlp_packed_floats(3);              // the largest layer: 6 x 16 x 64 x 4 floats = 96 KB
+// backward (dh = W^T dZ) fragments, steps 0..3 = layers fc, 3, 2, 1: [o tile of dZ][register][lane][k tile of dh]; layer 0 has no
+// input gradient (the positions are detached: gaussian_renderer/__init__.py:104) and layer 3 only its h part
+__host__ __device__ constexpr int mlp_bwd_tin(int s) { return s == 0 ? 1 : 4; }
+__host__ __device__ constexpr int mlp_bwd_floats(int s) { return mlp_bwd_tin(s) * 16 * 64 * 4; }
+__host__ __device__ constexpr int mlp_bwd_offset(int s) {
+  int o = MLP_PACKED;
+  for (int k = 0; k < s; k++) o += mlp_bwd_floats(k);
+  return o;
+}
+constexpr int MLP_PACKED_ALL = mlp_bwd_offset(4);
 
 __host__ __device__ constexpr int mlp_row_of_reg(int i) { return (i & 3) + 8 * (i >> 2); }
 
@@ -49,7 +60,23 @@ struct MlpWeights {   // the reference module's tensors (Conv1d weight [out][in]
 // one thread per packed float
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpWeights src, float *packed) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= MLP_PACKED) return;
+  if (e >= MLP_PACKED_ALL) return;
+  if (e >= MLP_PACKED) {   // backward fragments: W_l[o][column of input feature k]
+    int st = 0, base = MLP_PACKED;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (e >= mlp_bwd_offset(k)) {
+        st = k;
+        base = mlp_bwd_offset(k);
+      }
+    }
+    const int l = 4 - st, r = e - base;
+    const int t_out = r % 4, lane = (r / 4) % 64, i = (r / 4 / 64) % 16, t_in = r / 4 / 64 / 16;
+    const int o = 32 * t_in + mlp_row_of_reg(i) + 4 * (lane >> 5), kf = 32 * t_out + (lane & 31);
+    const int ncols = l == 3 ? MLP_E + MLP_W : MLP_W, col = l == 3 ? MLP_E + kf : kf, nrows = l == 4 ? MLP_OUT : MLP_W;
+    packed[e] = o < nrows ? src.w[l][(size_t)o * ncols + col] : 0.f;
+    return;
+  }
   if (e >= MLP_PACKED_W) {
     const int k = e - MLP_PACKED_W, l = k / MLP_W, o = k % MLP_W;
     packed[e] = l < 4 ? src.b[l][o] : (o < MLP_OUT ? src.b[4][o] : 0.f);
@@ -89,19 +116,12 @@ __device__ __forceinline__ float mlp_embed(int k, float x, float y, float z) {
   return r < 3 ? sinf(ang) : cosf(ang);
 }
 
-template <int L, int NIN>
-__device__ __forceinline__ void mlp_layer(const float *s_w, const float *bias, const f32x16 (&in)[NIN], f32x16 (&out)[mlp_tout(L)],
-                                          uint32_t lane) {
-  constexpr int NTO = mlp_tout(L);
-  static_assert(NIN == mlp_tin(L), "input tiles of the layer");
-  const uint32_t half = lane >> 5;
+// out[to] += A-fragments(s_w) x in[ti]: NTI input tiles (32 features each) -> NTO output tiles, 16 k-steps per input tile
+template <int NTI, int NTO>
+__device__ __forceinline__ void mlp_mm(const float *s_w, const f32x16 (&in)[NTI], f32x16 (&out)[NTO], uint32_t lane) {
+  static_assert(NTO == 4 || NTO == 1, "four output tiles (one 16-byte fragment read per k-step) or one");
 #pragma unroll
-  for (int t = 0; t < NTO; t++) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) out[t][i] = bias[32 * t + mlp_row_of_reg(i) + 4 * half];
-  }
-#pragma unroll
-  for (int ti = 0; ti < NIN; ti++) {
+  for (int ti = 0; ti < NTI; ti++) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       if constexpr (NTO == 4) {
@@ -118,6 +138,20 @@ __device__ __forceinline__ void mlp_layer(const float *s_w, const float *bias, c
   }
 }
 
+template <int L, int NIN>
+__device__ __forceinline__ void mlp_layer(const float *s_w, const float *bias, const f32x16 (&in)[NIN], f32x16 (&out)[mlp_tout(L)],
+                                          uint32_t lane) {
+  constexpr int NTO = mlp_tout(L);
+  static_assert(NIN == mlp_tin(L), "input tiles of the layer");
+  const uint32_t half = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NTO; t++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[t][i] = bias[32 * t + mlp_row_of_reg(i) + 4 * half];
+  }
+  mlp_mm<NIN, NTO>(s_w, in, out, lane);
+}
+
 __device__ __forceinline__ void mlp_relu(f32x16 (&t)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -126,13 +160,16 @@ __device__ __forceinline__ void mlp_relu(f32x16 (&t)[4]) {
   }
 }
 
-// all threads of the workgroup: the packed weights of layer L -> LDS (16-byte copies); barriers on both sides by the caller
+// all threads of the workgroup: a packed fragment block -> LDS (16-byte copies); barriers on both sides by the caller
+template <int OFFSET, int FLOATS>
+__device__ __forceinline__ void mlp_stage_block(const float *packed, float *s_w) {
+  const float4 *src = reinterpret_cast<const float4 *>(packed + OFFSET);
+  float4 *dst = reinterpret_cast<float4 *>(s_w);
+  for (int q = threadIdx.x; q < FLOATS / 4; q += 256) dst[q] = src[q];
+}
 template <int L>
 __device__ __forceinline__ void mlp_stage(const float *packed, float *s_w) {
-  const float4 *src = reinterpret_cast<const float4 *>(packed + mlp_packed_offset(L));
-  float4 *dst = reinterpret_cast<float4 *>(s_w);
-  constexpr int N4 = mlp_packed_floats(L) / 4;
-  for (int q = threadIdx.x; q < N4; q += 256) dst[q] = src[q];
+  mlp_stage_block<mlp_packed_offset(L), mlp_packed_floats(L)>(packed, s_w);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_forward_kernel(int P, const float *xyz, const float *packed,
@@ -192,11 +229,290 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward.  Two kernels:
+//   chain : per 32 points of a wave, the forward again (no activation was kept) -- every layer's output is written feature-major
+//           ([feature][point]: the lanes of a tile are consecutive points, so the stores coalesce) for the weight gradients and its
+//           ReLU mask kept as 64 bits per lane -- then dh = W^T dZ layer by layer with the SAME register chaining (the accumulator
+//           tile of dZ is the B operand; the A fragments are the transposed weights packed by mlp_pack_kernel), dZ written likewise;
+//   wgrad : dW_l[o][k] = sum_p dZ_l[o][p] X_{l-1}[k][p] -- both operands are now contiguous along p, which is the contraction index
+//           of this product: tiles of 32 points go through LDS (row stride 33: conflict-free operand reads) into A[i = o][kk = p]
+//           and B[kk = p][j = k] fragments; a workgroup owns a chunk of points of ONE layer and adds its partial dW / db with atomics.
+// Workspace rows (each Pp = P rounded up to 128 floats): emb 64 | h1 128 | h2 128 | h3 128 | h4 128 | dZ0..dZ3 4 x 128 | dOut^T 32.
+constexpr int MLP_WS_EMB = 0, MLP_WS_H1 = 64, MLP_WS_H4 = MLP_WS_H1 + 3 * MLP_W, MLP_WS_DZ0 = MLP_WS_H4 + MLP_W,
+              MLP_WS_DOUT = MLP_WS_DZ0 + 4 * MLP_W, MLP_WS_ROWS = MLP_WS_DOUT + 32;
+
+template <int NT>
+__device__ __forceinline__ void mlp_store_tiles(float *ws, size_t Pp, int row0, const f32x16 (&t)[NT], int pcol, uint32_t half) {
+#pragma unroll
+  for (int k = 0; k < NT; k++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) ws[(size_t)(row0 + 32 * k + mlp_row_of_reg(i) + 4 * (int)half) * Pp + pcol] = t[k][i];
+  }
+}
+__device__ __forceinline__ void mlp_relu_mask(f32x16 (&t)[4], uint32_t (&m)[2]) {   // relu in place, bit (16 k + i) % 32 of m[k / 2]
+  m[0] = m[1] = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const bool pos = t[k][i] > 0.f;
+      m[k / 2] |= pos ? (1u << ((16 * k + i) % 32)) : 0u;
+      t[k][i] = pos ? t[k][i] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void mlp_apply_mask(f32x16 (&t)[4], const uint32_t (&m)[2]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[k][i] = ((m[k / 2] >> ((16 * k + i) % 32)) & 1u) ? t[k][i] : 0.f;
+  }
+}
+__device__ __forceinline__ void mlp_zero(f32x16 (&t)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[k][i] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_backward_chain_kernel(
+    int P, int Pp_, const float *xyz, const float *packed, const float *dout, float *ws) {
+  extern __shared__ __attribute__((aligned(16))) float s_mlp[];
+  float *s_w = s_mlp, *s_b = s_mlp + MLP_LDS_FLOATS;
+  const size_t Pp = (size_t)Pp_;
+  const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, half = lane >> 5;
+  const int p = (int)(blockIdx.x * 128u + wave * 32u + (lane & 31u));   // < Pp always
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (p < P) {
+    x = xyz[(size_t)p * 3 + 0];
+    y = xyz[(size_t)p * 3 + 1];
+    z = xyz[(size_t)p * 3 + 2];
+  }
+  for (int q = threadIdx.x; q < MLP_PACKED_B; q += 256) s_b[q] = packed[MLP_PACKED_W + q];
+  mlp_stage<0>(packed, s_w);
+  f32x16 emb[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) emb[t][i] = mlp_embed(32 * t + mlp_row_of_reg(i) + 4 * (int)half, x, y, z);
+  }
+  mlp_store_tiles<2>(ws, Pp, MLP_WS_EMB, emb, p, half);
+  __syncthreads();
+  // ---- the forward again: outputs to the workspace, masks to registers
+  f32x16 a[4], b[4];
+  uint32_t m1[2], m2[2], m3[2], m4[2];
+  mlp_layer<0, 2>(s_w, s_b, emb, a, lane);
+  mlp_relu_mask(a, m1);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H1, a, p, half);
+  __syncthreads();
+  mlp_stage<1>(packed, s_w);
+  __syncthreads();
+  mlp_layer<1, 4>(s_w, s_b + MLP_W, a, b, lane);
+  mlp_relu_mask(b, m2);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H1 + MLP_W, b, p, half);
+  __syncthreads();
+  mlp_stage<2>(packed, s_w);
+  __syncthreads();
+  mlp_layer<2, 4>(s_w, s_b + 2 * MLP_W, b, a, lane);
+  mlp_relu_mask(a, m3);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H1 + 2 * MLP_W, a, p, half);
+  __syncthreads();
+  mlp_stage<3>(packed, s_w);
+  __syncthreads();
+  {
+    f32x16 cat[6] = {emb[0], emb[1], a[0], a[1], a[2], a[3]};
+    mlp_layer<3, 6>(s_w, s_b + 3 * MLP_W, cat, b, lane);
+  }
+  mlp_relu_mask(b, m4);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H4, b, p, half);
+  // ---- backward: dOut (rows = the 24 outputs, padded to 32) -> dh4 -> dZ3 -> dh3 -> dZ2 -> dh2 -> dZ1 -> dh1 -> dZ0
+  f32x16 d[1];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int row = mlp_row_of_reg(i) + 4 * (int)half;
+    d[0][i] = (row < MLP_OUT && p < P) ? dout[(size_t)p * MLP_OUT + row] : 0.f;
+  }
+  mlp_store_tiles<1>(ws, Pp, MLP_WS_DOUT, d, p, half);
+  __syncthreads();
+  mlp_stage_block<mlp_bwd_offset(0), mlp_bwd_floats(0)>(packed, s_w);
+  __syncthreads();
+  mlp_zero(a);
+  mlp_mm<1, 4>(s_w, d, a, lane);
+  mlp_apply_mask(a, m4);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + 3 * MLP_W, a, p, half);
+  __syncthreads();
+  mlp_stage_block<mlp_bwd_offset(1), mlp_bwd_floats(1)>(packed, s_w);
+  __syncthreads();
+  mlp_zero(b);
+  mlp_mm<4, 4>(s_w, a, b, lane);
+  mlp_apply_mask(b, m3);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + 2 * MLP_W, b, p, half);
+  __syncthreads();
+  mlp_stage_block<mlp_bwd_offset(2), mlp_bwd_floats(2)>(packed, s_w);
+  __syncthreads();
+  mlp_zero(a);
+  mlp_mm<4, 4>(s_w, b, a, lane);
+  mlp_apply_mask(a, m2);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + MLP_W, a, p, half);
+  __syncthreads();
+  mlp_stage_block<mlp_bwd_offset(3), mlp_bwd_floats(3)>(packed, s_w);
+  __syncthreads();
+  mlp_zero(b);
+  mlp_mm<4, 4>(s_w, a, b, lane);
+  mlp_apply_mask(b, m1);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0, b, p, half);
+}
+
+struct MlpWgradLayer {
+  int a_row, ta;            // dZ rows in the workspace, tiles of 32
+  int b_row0, tb0, b_row1;  // X rows: tb0 tiles from b_row0, the rest from b_row1
+  int tb;
+  float *dW, *db;
+  int nrows, ncols, kind;   // kind 0: column = k (k < ncols); 3: layer 3's [emb(63) | pad | h(128)] columns
+};
+struct MlpWgradArgs {
+  MlpWgradLayer L[MLP_LAYERS];
+  const float *ws;
+  int Pp, chunk;
+};
+constexpr int WG_STRIDE = 33;   // floats per staged row of 32 points
+
+template <int TA, int TB>
+__device__ __forceinline__ void mlp_wgrad_body(const MlpWgradLayer &L, const float *ws, size_t Pp, int p0, int p1, float *s_A, float *s_B) {
+  constexpr int NACC = TA == 4 ? TB : 1;   // TA == 4: wave w owns dZ tile w and every X tile; TA == 1 (fc): X tile w
+  const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, half = lane >> 5, r = lane & 31u;
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[k][i] = 0.f;
+  }
+  float dbsum = 0.f;
+  const int my_ta = TA == 4 ? (int)wave : 0;
+  for (int pb = p0; pb < p1; pb += 32) {
+    // stage [rows][32 points]: eight threads per row, 16 bytes each
+    for (int q = threadIdx.x; q < (TA + TB) * 32 * 8; q += 256) {
+      const int row = q / 8, c4 = (q % 8) * 4;
+      const bool isA = row < TA * 32;
+      const int rb = row - TA * 32;
+      const int src_row = isA ? L.a_row + row : (rb < L.tb0 * 32 ? L.b_row0 + rb : L.b_row1 + (rb - L.tb0 * 32));
+      const float4 v = *reinterpret_cast<const float4 *>(&ws[(size_t)src_row * Pp + pb + c4]);
+      float *dst = (isA ? s_A + row * WG_STRIDE : s_B + rb * WG_STRIDE) + c4;
+      dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const float af = s_A[(32 * my_ta + (int)r) * WG_STRIDE + 2 * s + (int)half];
+      if constexpr (TA == 4) {
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) {
+          const float bf = s_B[(32 * tb + (int)r) * WG_STRIDE + 2 * s + (int)half];
+          acc[tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[tb], 0, 0, 0);
+        }
+      } else {
+        const float bf = s_B[(32 * (int)wave + (int)r) * WG_STRIDE + 2 * s + (int)half];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[0], 0, 0, 0);
+      }
+    }
+    if ((int)threadIdx.x < TA * 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; c++) t += s_A[(int)threadIdx.x * WG_STRIDE + c];
+      dbsum += t;
+    }
+    __syncthreads();
+  }
+  // D[i = o][j = k]: column on the lane, rows in the registers
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+    const int tb = TA == 4 ? k : (int)wave;
+    const int kf = 32 * tb + (int)r;
+    int col = kf;
+    if (L.kind == 3) col = kf < MLP_E ? kf : (kf == MLP_E ? -1 : MLP_E + (kf - 64));
+    if (col >= L.ncols) col = -1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int o = 32 * my_ta + mlp_row_of_reg(i) + 4 * (int)half;
+      if (col >= 0 && o < L.nrows) atomicAdd(&L.dW[(size_t)o * L.ncols + col], acc[k][i]);
+    }
+  }
+  if ((int)threadIdx.x < TA * 32 && (int)threadIdx.x < L.nrows) atomicAdd(&L.db[threadIdx.x], dbsum);
+}
+
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(const MlpWgradArgs a) {
+  __shared__ float s_A[128 * WG_STRIDE];
+  __shared__ float s_B[192 * WG_STRIDE];
+  const MlpWgradLayer &L = a.L[blockIdx.y];
+  const int p0 = (int)blockIdx.x * a.chunk, p1 = min(a.Pp, p0 + a.chunk);
+  if (p0 >= p1) return;
+  switch (blockIdx.y) {
+    case 0: mlp_wgrad_body<4, 2>(L, a.ws, (size_t)a.Pp, p0, p1, s_A, s_B); break;
+    case 3: mlp_wgrad_body<4, 6>(L, a.ws, (size_t)a.Pp, p0, p1, s_A, s_B); break;
+    case 4: mlp_wgrad_body<1, 4>(L, a.ws, (size_t)a.Pp, p0, p1, s_A, s_B); break;
+    default: mlp_wgrad_body<4, 4>(L, a.ws, (size_t)a.Pp, p0, p1, s_A, s_B); break;
+  }
+}
+
 }  // namespace gsr
 
 extern "C" {
 
-size_t gsr_lbs_offset_mlp_packed_floats(void) { return (size_t)gsr::MLP_PACKED; }
+size_t gsr_lbs_offset_mlp_packed_floats(void) { return (size_t)gsr::MLP_PACKED_ALL; }
+
+size_t gsr_lbs_offset_mlp_backward_workspace_floats(int P) {
+  const size_t Pp = ((size_t)(P > 0 ? P : 0) + 127) / 128 * 128;
+  return (size_t)gsr::MLP_WS_ROWS * Pp;
+}
+
+int gsr_lbs_offset_mlp_backward(int P, const float *xyz, const float *packed, const float *dL_dout, float *workspace,
+                                float *const *dL_dweights, float *const *dL_dbiases, gsr_stream_t stream_) {
+  using namespace gsr;
+  if (P < 0 || (P > 0 && (!xyz || !packed || !dL_dout || !workspace || !dL_dweights || !dL_dbiases))) {
+    set_error("gsr_lbs_offset_mlp_backward: bad size or null pointer");
+    return GSR_EINVAL;
+  }
+  if (reinterpret_cast<size_t>(packed) % 16 != 0 || reinterpret_cast<size_t>(workspace) % 16 != 0) {
+    set_error("gsr_lbs_offset_mlp_backward: the packed weights and the workspace must be 16-byte aligned");
+    return GSR_EINVAL;
+  }
+  for (int l = 0; l < MLP_LAYERS; l++) {
+    if (P > 0 && (!dL_dweights[l] || !dL_dbiases[l])) {
+      set_error("gsr_lbs_offset_mlp_backward: layer %d: null gradient array", l);
+      return GSR_EINVAL;
+    }
+  }
+  if (P == 0) return GSR_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int Pp = (P + 127) / 128 * 128;
+  constexpr size_t lds = (size_t)(MLP_LDS_FLOATS + MLP_PACKED_B) * sizeof(float);
+  GSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  hipLaunchKernelGGL(mlp_backward_chain_kernel, dim3((unsigned)(Pp / 128)), dim3(256), lds, stream, P, Pp, xyz, packed, dL_dout, workspace);
+  GSR_HIP(hipGetLastError());
+  MlpWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ws = workspace, a.Pp = Pp, a.chunk = 1024;
+  const int xrow[5] = {MLP_WS_EMB, MLP_WS_H1, MLP_WS_H1 + MLP_W, MLP_WS_EMB, MLP_WS_H4};
+  for (int l = 0; l < MLP_LAYERS; l++) {
+    MlpWgradLayer &L = a.L[l];
+    L.a_row = l < 4 ? MLP_WS_DZ0 + l * MLP_W : MLP_WS_DOUT;
+    L.ta = l < 4 ? 4 : 1;
+    L.b_row0 = xrow[l];
+    L.tb = mlp_tin(l);
+    L.tb0 = l == 3 ? 2 : L.tb;
+    L.b_row1 = MLP_WS_H1 + 2 * MLP_W;   // layer 3: h3 behind the embedding
+    L.dW = dL_dweights[l], L.db = dL_dbiases[l];
+    L.nrows = l < 4 ? MLP_W : MLP_OUT;
+    L.ncols = l == 0 ? MLP_E : (l == 3 ? MLP_E + MLP_W : MLP_W);
+    L.kind = l == 3 ? 3 : 0;
+  }
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)((Pp + a.chunk - 1) / a.chunk), MLP_LAYERS), dim3(256), 0, stream, a);
+  return check_hip(hipGetLastError(), "mlp_wgrad_kernel", __FILE__, __LINE__);
+}
+
 
 int gsr_lbs_offset_mlp_pack(const float *const *weights, const float *const *biases, float *packed, gsr_stream_t stream_) {
   using namespace gsr;
@@ -214,7 +530,7 @@ int gsr_lbs_offset_mlp_pack(const float *const *weights, const float *const *bia
     w.b[l] = biases[l];
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3((MLP_PACKED + 255) / 256), dim3(256), 0, stream, w, packed);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3((MLP_PACKED_ALL + 255) / 256), dim3(256), 0, stream, w, packed);
   return check_hip(hipGetLastError(), "mlp_pack_kernel", __FILE__, __LINE__);
 }
 

@@ -60,36 +60,6 @@ class LbsOffsetDecoder(torch.nn.Module):
         return out.t()[None]
 
 
-class LbsOffsetMLP(torch.nn.Module):
-    """xyz [1,P,3] -> [1,24,P] through a network of the REFERENCE'S SIZE (nets/mlp_delta_weight_lbs.py: 63-d embedding of the
-    position over ten frequency octaves, 63 -> 128 -> 128 -> 128, the embedding joined again, 191 -> 128, 128 -> 24, ReLU between),
-    written here as row-major linear layers on [P, C] (the reference runs Conv1d(1) on [1, C, P]).  Random-init, not the reference's
-    module: it exists for ONE figure -- what the render() training step costs with a per-Gaussian network of that size in it
-    (`bench.py: extra.render_200k.with_reference_sized_decoder`) -- next to the affine stand-in the other figures use."""
-
-    def __init__(self, width=128, octaves=10, seed=1):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        E = 3 + 3 * 2 * octaves
-        dims = [(E, width), (width, width), (width, width), (width + E, width)]
-        self.w = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(i, o, generator=g) * math.sqrt(2.0 / i)) for i, o in dims])
-        self.b = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(o)) for _, o in dims])
-        self.w_out = torch.nn.Parameter(1e-2 * torch.randn(width, 24, generator=g) / math.sqrt(width))
-        self.b_out = torch.nn.Parameter(torch.zeros(24))
-        self.register_buffer("freqs", 2.0 ** torch.arange(octaves, dtype=torch.float32))
-
-    def forward(self, xyz):
-        x = xyz[0]                                              # [P, 3]
-        ang = x[:, None, :] * self.freqs[:, None]               # [P, octaves, 3]
-        emb = torch.cat((x, torch.stack((torch.sin(ang), torch.cos(ang)), dim=2).reshape(x.shape[0], -1)), dim=1)   # [P, 63]
-        h = emb
-        for k in range(4):
-            if k == 3:
-                h = torch.cat((emb, h), dim=1)
-            h = torch.relu(torch.addmm(self.b[k], h, self.w[k]))
-        return torch.addmm(self.b_out, h, self.w_out).t()[None]
-
-
 def body_arrays(V=6890, seed=0):
     rng = np.random.default_rng(seed)
     vt = rng.uniform(-1, 1, (V, 3)).astype(np.float32) * np.array([0.45, 0.9, 0.15], np.float32)
@@ -126,7 +96,8 @@ def view_camera(body, W, H, view, n_views=8, device="cuda", radius=2.4, fov_deg=
 
 def build(P, V=6890, device="cuda", seed=0, motion=False, sh_degree=3, decoder="affine"):
     """(model, body arrays).  model.SMPL_NEUTRAL holds the body tables as device tensors; motion=True attaches the two decoders
-    (decoder = "affine": the 96-parameter stand-in; "reference_size": LbsOffsetMLP)."""
+    (decoder = "affine": the 96-parameter stand-in; "reference_size": nets.FusedLBSOffsetDecoder -- the reference network's layers,
+    random init -- on the fused kernels; "reference_size_torch": the same module in torch ops)."""
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
     body = body_arrays(V, seed)
     smpl = {k: d(v) for k, v in body.items()}
@@ -135,5 +106,14 @@ def build(P, V=6890, device="cuda", seed=0, motion=False, sh_degree=3, decoder="
                                            device=device, seed=seed)
     if motion:
         model.pose_decoder = PoseRefiner().to(device)
-        model.lweight_offset_decoder = (LbsOffsetMLP() if decoder == "reference_size" else LbsOffsetDecoder()).to(device)
+        if decoder in ("reference_size", "reference_size_torch"):
+            from .nets import FusedLBSOffsetDecoder
+            torch.manual_seed(seed + 7)
+            net = FusedLBSOffsetDecoder().to(device)
+            with torch.no_grad():
+                net.bw_fc.weight.mul_(0.05)      # small offsets around the SMPL weights, like a network early in training
+            net.use_fused = decoder == "reference_size"
+            model.lweight_offset_decoder = net
+        else:
+            model.lweight_offset_decoder = LbsOffsetDecoder().to(device)
     return model, body

@@ -6,10 +6,10 @@
 
 The reference runs this network on every Gaussian every frame when motion_offset_flag is set (gaussian_renderer/__init__.py:100-106):
 a 63-d positional embedding through 63-128-128-128-(63+128)-128-24 with ReLU -- 27 GFLOP forward at 200k points, which plain torch
-spends in skinny fp32 GEMMs and 100-MB elementwise kernels.  When no gradient is being recorded (render.py,
-evaluation, every eval_*.sh of the reference) forward() is ONE kernel on the matrix cores: f32 MFMA, activations in registers, the
-same accuracy as the torch ops.  While gradients are recorded the same arithmetic runs in torch ops (the fused backward is not built).
-Tensors must live on the GPU for the fused path; there is no CPU path for it.
+spends in skinny fp32 GEMMs and 100-MB elementwise kernels.  Here forward() is ONE kernel on the matrix cores (f32 MFMA, activations
+in registers, the accuracy of the torch ops) and the backward two (the forward again + dh = W^T dZ chained the same way; the
+weight gradients as products over the points).  render() hands the positions in DETACHED (:104): a `pts` that requires grad takes
+the same arithmetic in torch ops instead (forward_torch).  Tensors must live on the GPU: there is no CPU path for the fused kernels.
 """
 import ctypes as C
 
@@ -38,6 +38,7 @@ class FusedLBSOffsetDecoder(torch.nn.Module):
                                                torch.nn.Conv1d(W + E, W, 1)])
         self.bw_fc = torch.nn.Conv1d(W, total_bones, 1)
         self._packed, self._packed_key = None, None
+        self.use_fused = True   # False: the same arithmetic in torch ops (forward_torch), for comparison
 
     def _layers(self):
         return list(self.bw_linears) + [self.bw_fc]
@@ -50,13 +51,7 @@ class FusedLBSOffsetDecoder(torch.nn.Module):
             for t in ts:
                 if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                     raise RuntimeError("FusedLBSOffsetDecoder: parameters must be contiguous float32 tensors on a HIP device")
-            n = int(lib.gsr_lbs_offset_mlp_packed_floats())
-            if self._packed is None or self._packed.device != dev:
-                self._packed = torch.empty(n, dtype=torch.float32, device=dev)
-            mk = lambda xs: (C.c_void_p * 5)(*[x.data_ptr() for x in xs])  # noqa: E731  (host arrays of device pointers)
-            with torch.cuda.device(dev):
-                check(lib.gsr_lbs_offset_mlp_pack(mk([m.weight for m in self._layers()]), mk([m.bias for m in self._layers()]),
-                                                  ptr(self._packed), torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_offset_mlp_pack")
+            self._packed = _pack(ts, dev, None if (self._packed is None or self._packed.device != dev) else self._packed)
             self._packed_key = key
         return self._packed
 
@@ -72,17 +67,58 @@ class FusedLBSOffsetDecoder(torch.nn.Module):
 
     def forward(self, pts):
         """pts [1, P, 3] -> [1, 24, P]."""
-        needs_grad = torch.is_grad_enabled() and (pts.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if needs_grad:
-            return self.forward_torch(pts)
+        if not self.use_fused or (torch.is_grad_enabled() and pts.requires_grad):
+            return self.forward_torch(pts)   # (an input gradient is not built: render() detaches the positions)
         if not pts.is_cuda:
             raise RuntimeError("FusedLBSOffsetDecoder: tensors must live on a HIP device (no CPU path)")
-        dev = pts.device
         x = pts[0].detach().contiguous().float()
-        P = x.shape[0]
-        out = torch.empty((P, self.total_bones), dtype=torch.float32, device=dev)
-        packed = self._packed_weights(dev)
+        params = [t for m in self._layers() for t in (m.weight, m.bias)]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _FusedOffsetNet.apply(x, *params).t()[None]
+        return _forward_fused(x, self._packed_weights(x.device)).t()[None]
+
+
+def _pack(params, dev, out=None):
+    n = int(lib.gsr_lbs_offset_mlp_packed_floats())
+    packed = torch.empty(n, dtype=torch.float32, device=dev) if out is None else out
+    mk = lambda xs: (C.c_void_p * 5)(*[x.data_ptr() for x in xs])  # noqa: E731  (host arrays of device pointers)
+    with torch.cuda.device(dev):
+        check(lib.gsr_lbs_offset_mlp_pack(mk(params[0::2]), mk(params[1::2]), ptr(packed), torch.cuda.current_stream(dev).cuda_stream),
+              "gsr_lbs_offset_mlp_pack")
+    return packed
+
+
+def _forward_fused(x, packed):
+    out = torch.empty((x.shape[0], 24), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.gsr_lbs_offset_mlp_forward(x.shape[0], ptr(x), ptr(packed), ptr(out), torch.cuda.current_stream(x.device).cuda_stream),
+              "gsr_lbs_offset_mlp_forward")
+    return out
+
+
+class _FusedOffsetNet(torch.autograd.Function):
+    """x [P, 3] (no gradient), the ten parameter tensors -> [P, 24]; backward = gsr_lbs_offset_mlp_backward."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ps = [p.detach() for p in params]
+        for t in ps:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise RuntimeError("FusedLBSOffsetDecoder: parameters must be contiguous float32 tensors on a HIP device")
+        packed = _pack(ps, x.device)   # a buffer of its own: it must still describe THESE parameters when backward runs
+        ctx.save_for_backward(x, packed)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return _forward_fused(x, packed)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, packed = ctx.saved_tensors
+        dev, P = x.device, x.shape[0]
+        g = g.contiguous().float()
+        grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
+        ws = torch.empty(int(lib.gsr_lbs_offset_mlp_backward_workspace_floats(P)), dtype=torch.float32, device=dev)
+        mk = lambda xs: (C.c_void_p * 5)(*[t.data_ptr() for t in xs])  # noqa: E731
         with torch.cuda.device(dev):
-            check(lib.gsr_lbs_offset_mlp_forward(P, ptr(x), ptr(packed), ptr(out), torch.cuda.current_stream(dev).cuda_stream),
-                  "gsr_lbs_offset_mlp_forward")
-        return out.t()[None]
+            check(lib.gsr_lbs_offset_mlp_backward(P, ptr(x), ptr(packed), ptr(g), ptr(ws), mk(grads[0::2]), mk(grads[1::2]),
+                                                  torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_offset_mlp_backward")
+        return (None, *grads)

@@ -24,3 +24,18 @@ for P in (50_000, 200_000, 500_000):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
             print(f"P={P:7d} {name:10s} {dt * 1e3:8.3f} ms   {137e3 * P / dt / 1e12:6.1f} TFLOP/s", flush=True)
+    w = torch.randn(1, 24, P, device="cuda")
+    for name, fn in (("fused", lambda: dec(pts)), ("torch ops", lambda: dec.forward_torch(pts))):
+        def step():
+            for p in dec.parameters():
+                p.grad = None
+            (fn() * w).sum().backward()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        print(f"P={P:7d} {name:10s} forward + backward {(time.perf_counter() - t0) / n * 1e3:8.3f} ms", flush=True)
