@@ -23,6 +23,10 @@ namespace gsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+constexpr int MLP_WG = 512;            // threads per workgroup of the forward / chain kernels: eight waves (two per SIMD: the second hides
+                                       // the first's LDS reads and the barriers around the weight staging), 32 points each
+constexpr int MLP_WG_POINTS = MLP_WG / 2;
+
 constexpr int MLP_LAYERS = 5;
 constexpr int MLP_E = 63, MLP_W = 128, MLP_OUT = 24;
 // per layer: input tiles of 32 features, output tiles of 32 features
@@ -138,6 +142,16 @@ __device__ __forceinline__ void mlp_mm(const float *s_w, const f32x16 (&in)[NTI]
   }
 }
 
+// the embedding as two activation tiles (features 0..31, 32..63); a template recursion: left as a loop the compiler does not unroll
+// the 32 inlined sin / cos evaluations and puts the tile array into scratch
+template <int K = 0>
+__device__ __forceinline__ void mlp_embed_tiles(f32x16 (&emb)[2], int half, float x, float y, float z) {
+  if constexpr (K < 32) {
+    emb[K / 16][K % 16] = mlp_embed(32 * (K / 16) + mlp_row_of_reg(K % 16) + 4 * half, x, y, z);
+    mlp_embed_tiles<K + 1>(emb, half, x, y, z);
+  }
+}
+
 template <int L, int NIN>
 __device__ __forceinline__ void mlp_layer(const float *s_w, const float *bias, const f32x16 (&in)[NIN], f32x16 (&out)[mlp_tout(L)],
                                           uint32_t lane) {
@@ -165,34 +179,29 @@ template <int OFFSET, int FLOATS>
 __device__ __forceinline__ void mlp_stage_block(const float *packed, float *s_w) {
   const float4 *src = reinterpret_cast<const float4 *>(packed + OFFSET);
   float4 *dst = reinterpret_cast<float4 *>(s_w);
-  for (int q = threadIdx.x; q < FLOATS / 4; q += 256) dst[q] = src[q];
+  for (int q = threadIdx.x; q < FLOATS / 4; q += MLP_WG) dst[q] = src[q];
 }
 template <int L>
 __device__ __forceinline__ void mlp_stage(const float *packed, float *s_w) {
   mlp_stage_block<mlp_packed_offset(L), mlp_packed_floats(L)>(packed, s_w);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_forward_kernel(int P, const float *xyz, const float *packed,
+__global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_forward_kernel(int P, const float *xyz, const float *packed,
                                                                                                    float *out) {
   extern __shared__ __attribute__((aligned(16))) float s_mlp[];   // MLP_LDS_FLOATS weights + MLP_PACKED_B biases
   float *s_w = s_mlp, *s_b = s_mlp + MLP_LDS_FLOATS;
   const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, half = lane >> 5;
-  const int p = (int)(blockIdx.x * 128u + wave * 32u + (lane & 31u));
+  const int p = (int)(blockIdx.x * (uint32_t)MLP_WG_POINTS + wave * 32u + (lane & 31u));
   float x = 0.f, y = 0.f, z = 0.f;
   if (p < P) {
     x = xyz[(size_t)p * 3 + 0];
     y = xyz[(size_t)p * 3 + 1];
     z = xyz[(size_t)p * 3 + 2];
   }
-  for (int q = threadIdx.x; q < MLP_PACKED_B; q += 256) s_b[q] = packed[MLP_PACKED_W + q];
+  for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
   mlp_stage<0>(packed, s_w);
-  // the embedding as two activation tiles (features 0..31, 32..63)
   f32x16 emb[2];
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) emb[t][i] = mlp_embed(32 * t + mlp_row_of_reg(i) + 4 * (int)half, x, y, z);
-  }
+  mlp_embed_tiles(emb, (int)half, x, y, z);
   __syncthreads();
   f32x16 a[4], b[4];
   mlp_layer<0, 2>(s_w, s_b, emb, a, lane);
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   wgrad : dW_l[o][k] = sum_p dZ_l[o][p] X_{l-1}[k][p] -- both operands are now contiguous along p, which is the contraction index
 //           of this product: tiles of 32 points go through LDS (row stride 33: conflict-free operand reads) into A[i = o][kk = p]
 //           and B[kk = p][j = k] fragments; a workgroup owns a chunk of points of ONE layer and adds its partial dW / db with atomics.
-// Workspace rows (each Pp = P rounded up to 128 floats): emb 64 | h1 128 | h2 128 | h3 128 | h4 128 | dZ0..dZ3 4 x 128 | dOut^T 32.
+// Workspace rows (each Pp = P rounded up to a workgroup's 256 points, floats): emb 64 | h1 128 | h2 128 | h3 128 | h4 128 | dZ0..dZ3 4 x 128 | dOut^T 32.
 constexpr int MLP_WS_EMB = 0, MLP_WS_H1 = 64, MLP_WS_H4 = MLP_WS_H1 + 3 * MLP_W, MLP_WS_DZ0 = MLP_WS_H4 + MLP_W,
               MLP_WS_DOUT = MLP_WS_DZ0 + 4 * MLP_W, MLP_WS_ROWS = MLP_WS_DOUT + 32;
 
@@ -277,27 +286,23 @@ __device__ __forceinline__ void mlp_zero(f32x16 (&t)[4]) {
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_backward_chain_kernel(
+__global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_backward_chain_kernel(
     int P, int Pp_, const float *xyz, const float *packed, const float *dout, float *ws) {
   extern __shared__ __attribute__((aligned(16))) float s_mlp[];
   float *s_w = s_mlp, *s_b = s_mlp + MLP_LDS_FLOATS;
   const size_t Pp = (size_t)Pp_;
   const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, half = lane >> 5;
-  const int p = (int)(blockIdx.x * 128u + wave * 32u + (lane & 31u));   // < Pp always
+  const int p = (int)(blockIdx.x * (uint32_t)MLP_WG_POINTS + wave * 32u + (lane & 31u));   // < Pp always
   float x = 0.f, y = 0.f, z = 0.f;
   if (p < P) {
     x = xyz[(size_t)p * 3 + 0];
     y = xyz[(size_t)p * 3 + 1];
     z = xyz[(size_t)p * 3 + 2];
   }
-  for (int q = threadIdx.x; q < MLP_PACKED_B; q += 256) s_b[q] = packed[MLP_PACKED_W + q];
+  for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
   mlp_stage<0>(packed, s_w);
   f32x16 emb[2];
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) emb[t][i] = mlp_embed(32 * t + mlp_row_of_reg(i) + 4 * (int)half, x, y, z);
-  }
+  mlp_embed_tiles(emb, (int)half, x, y, z);
   mlp_store_tiles<2>(ws, Pp, MLP_WS_EMB, emb, p, half);
   __syncthreads();
   // ---- the forward again: outputs to the workspace, masks to registers
@@ -391,18 +396,37 @@ __device__ __forceinline__ void mlp_wgrad_body(const MlpWgradLayer &L, const flo
   }
   float dbsum = 0.f;
   const int my_ta = TA == 4 ? (int)wave : 0;
-  for (int pb = p0; pb < p1; pb += 32) {
-    // stage [rows][32 points]: eight threads per row, 16 bytes each
-    for (int q = threadIdx.x; q < (TA + TB) * 32 * 8; q += 256) {
-      const int row = q / 8, c4 = (q % 8) * 4;
-      const bool isA = row < TA * 32;
-      const int rb = row - TA * 32;
-      const int src_row = isA ? L.a_row + row : (rb < L.tb0 * 32 ? L.b_row0 + rb : L.b_row1 + (rb - L.tb0 * 32));
-      const float4 v = *reinterpret_cast<const float4 *>(&ws[(size_t)src_row * Pp + pb + c4]);
-      float *dst = (isA ? s_A + row * WG_STRIDE : s_B + rb * WG_STRIDE) + c4;
-      dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+  // a stage = [rows][32 points], eight threads per row with 16 bytes each; the NEXT stage's global loads are issued before this
+  // stage's MFMAs and land in LDS after them (the loads' latency used to sit exposed between two barriers)
+  constexpr int NQ = ((TA + TB) * 32 * 8 + 255) / 256;   // 16-byte pieces per thread per stage
+  float4 pre[NQ];
+  auto fetch = [&](int pb) {
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+      const int q = (int)threadIdx.x + j * 256;
+      if (q < (TA + TB) * 32 * 8) {
+        const int row = q / 8, c4 = (q % 8) * 4, rb = row - TA * 32;
+        const int src_row = row < TA * 32 ? L.a_row + row : (rb < L.tb0 * 32 ? L.b_row0 + rb : L.b_row1 + (rb - L.tb0 * 32));
+        pre[j] = *reinterpret_cast<const float4 *>(&ws[(size_t)src_row * Pp + pb + c4]);
+      }
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+      const int q = (int)threadIdx.x + j * 256;
+      if (q < (TA + TB) * 32 * 8) {
+        const int row = q / 8, c4 = (q % 8) * 4, rb = row - TA * 32;
+        float *dst = (row < TA * 32 ? s_A + row * WG_STRIDE : s_B + rb * WG_STRIDE) + c4;
+        dst[0] = pre[j].x, dst[1] = pre[j].y, dst[2] = pre[j].z, dst[3] = pre[j].w;
+      }
+    }
+  };
+  fetch(p0);
+  for (int pb = p0; pb < p1; pb += 32) {
+    commit();
     __syncthreads();
+    if (pb + 32 < p1) fetch(pb + 32);
 #pragma unroll
     for (int s = 0; s < 16; s++) {
       const float af = s_A[(32 * my_ta + (int)r) * WG_STRIDE + 2 * s + (int)half];
@@ -463,7 +487,7 @@ extern "C" {
 size_t gsr_lbs_offset_mlp_packed_floats(void) { return (size_t)gsr::MLP_PACKED_ALL; }
 
 size_t gsr_lbs_offset_mlp_backward_workspace_floats(int P) {
-  const size_t Pp = ((size_t)(P > 0 ? P : 0) + 127) / 128 * 128;
+  const size_t Pp = ((size_t)(P > 0 ? P : 0) + gsr::MLP_WG_POINTS - 1) / gsr::MLP_WG_POINTS * gsr::MLP_WG_POINTS;
   return (size_t)gsr::MLP_WS_ROWS * Pp;
 }
 
@@ -486,11 +510,12 @@ int gsr_lbs_offset_mlp_backward(int P, const float *xyz, const float *packed, co
   }
   if (P == 0) return GSR_OK;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  const int Pp = (P + 127) / 128 * 128;
+  const int Pp = (P + MLP_WG_POINTS - 1) / MLP_WG_POINTS * MLP_WG_POINTS;
   constexpr size_t lds = (size_t)(MLP_LDS_FLOATS + MLP_PACKED_B) * sizeof(float);
   GSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
-  hipLaunchKernelGGL(mlp_backward_chain_kernel, dim3((unsigned)(Pp / 128)), dim3(256), lds, stream, P, Pp, xyz, packed, dL_dout, workspace);
+  hipLaunchKernelGGL(mlp_backward_chain_kernel, dim3((unsigned)(Pp / MLP_WG_POINTS)), dim3(MLP_WG), lds, stream, P, Pp, xyz, packed, dL_dout,
+                     workspace);
   GSR_HIP(hipGetLastError());
   MlpWgradArgs a;
   memset(&a, 0, sizeof(a));
@@ -550,7 +575,8 @@ int gsr_lbs_offset_mlp_forward(int P, const float *xyz, const float *packed, flo
   static_assert(lds <= 160 * 1024, "one layer's packed weights fit the LDS of a CU");
   // (dynamic LDS above 64 KB needs the attribute; set per call: it is per device and costs nothing)
   GSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), lds, stream, P, xyz, packed, out);
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((P + MLP_WG_POINTS - 1) / MLP_WG_POINTS)), dim3(MLP_WG), lds, stream, P, xyz, packed,
+                     out);
   return check_hip(hipGetLastError(), "mlp_forward_kernel", __FILE__, __LINE__);
 }
 

@@ -64,16 +64,21 @@ def test_fused_offset_decoder_parameter_gradients_match_float64_autograd(P):
     assert out.grad_fn is not None and type(out.grad_fn).__name__ != "AddmmBackward0"
     (out * w).sum().backward()
     got = [p.grad.clone() for p in dec.parameters()]
+    for p in dec.parameters():
+        p.grad = None
+    (dec.forward_torch(pts) * w).sum().backward()          # the same network in torch's own f32 ops
+    t32 = [p.grad.clone() for p in dec.parameters()]
     dec64 = FusedLBSOffsetDecoder().cuda().double()
     dec64.load_state_dict({k: v.double() for k, v in dec.state_dict().items()})
     (dec64.forward_torch(pts.double()) * w.double()).sum().backward()
-    for (name, _), a, b in zip(dec.named_parameters(), got, [p.grad for p in dec64.parameters()]):
+    for (name, _), a, t, b in zip(dec.named_parameters(), got, t32, [p.grad for p in dec64.parameters()]):
         scale = float(b.abs().max())
-        err = float((a.double() - b).abs().max())
-        # 1e-5 of the tensor's largest entry up to a few thousand points (every index right, f32 sums in arbitrary atomic order).  At
-        # 70k points (36 M pre-activations) a few dozen of them lie within f32 rounding of zero and take the other side of the ReLU
-        # than the float64 evaluation does -- each moves a sum by O(1) of 35k: 3e-4 there (measured 1.0e-4 on a bias, 6e-5 on a weight)
-        assert scale > 0 and err <= (1e-5 if P <= 3000 else 3e-4) * scale, (name, err / scale)
+        err, err32 = float((a.double() - b).abs().max()) / scale, float((t.double() - b).abs().max()) / scale
+        # 1e-5 of the tensor's largest entry (measured 2e-7 .. 1e-6 up to 3,000 points: every index right, f32 sums in arbitrary atomic
+        # order).  At 70k points a few of the 36 M pre-activations lie within f32 rounding of zero and take the other side of the ReLU
+        # than the float64 evaluation does, each moving a sum by O(1): torch's own f32 ops are then 2e-4 .. 7e-4 off float64, the
+        # fused kernels 4e-5 .. 4e-4 -- so the bound is "no worse than twice torch's f32 error" where that is larger
+        assert scale > 0 and err <= max(1e-5, 2.0 * err32), (name, err, err32)
 
 
 def test_fused_offset_decoder_repacks_after_a_parameter_update_and_trains():
