@@ -30,11 +30,13 @@ GRAPH_REPLAY_SAFE = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 __version__ = "0.1.0"
 
 
-def install_dropin(render=False):
+def install_dropin(render=False, nets=False):
     """Make `import diff_gaussian_rasterization`, `from simple_knn._C import distCUDA2`, `from knn_cuda import KNN` resolve
     to this package.  render=True also registers `gaussian_renderer` (train.py:17 / render.py import `render` -- and train.py
     `network_gui` -- from it), so that the reference's own drivers reach the fused render() without an edit; the reference's
-    gaussian_renderer module must then not have been imported before."""
+    gaussian_renderer module must then not have been imported before.  nets=True registers `nets.mlp_delta_weight_lbs`
+    (scene/gaussian_model.py:27 imports LBSOffsetDecoder from it): the skinning-offset network on the fused kernels, same
+    constructor, same state_dict keys."""
     pairs = [("diff_gaussian_rasterization", "mygauhuman_amd.diff_gaussian_rasterization"),
              ("simple_knn", "mygauhuman_amd.simple_knn"),
              ("simple_knn._C", "mygauhuman_amd.simple_knn._C"),
@@ -42,5 +44,7 @@ def install_dropin(render=False):
     if render:
         pairs += [("gaussian_renderer", "mygauhuman_amd.gaussian_renderer"),
                   ("gaussian_renderer.network_gui", "mygauhuman_amd.gaussian_renderer.network_gui")]
+    if nets:
+        pairs += [("nets.mlp_delta_weight_lbs", "mygauhuman_amd.nets")]
     for theirs, ours in pairs:
         sys.modules[theirs] = importlib.import_module(ours)

@@ -122,3 +122,6 @@ class _FusedOffsetNet(torch.autograd.Function):
             check(lib.gsr_lbs_offset_mlp_backward(P, ptr(x), ptr(packed), ptr(g), ptr(ws), mk(grads[0::2]), mk(grads[1::2]),
                                                   torch.cuda.current_stream(dev).cuda_stream), "gsr_lbs_offset_mlp_backward")
         return (None, *grads)
+
+
+LBSOffsetDecoder = FusedLBSOffsetDecoder   # the reference's class name (`from nets.mlp_delta_weight_lbs import LBSOffsetDecoder`)

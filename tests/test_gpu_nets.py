@@ -99,7 +99,7 @@ def test_fused_offset_decoder_repacks_after_a_parameter_update_and_trains():
         loss = (dec(pts) - target).square().mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0] and all(np.isfinite(losses))
     with torch.no_grad():                  # and a pts that requires grad takes the torch ops (input gradient not built)
         ref = dec(pts)
@@ -117,3 +117,29 @@ def test_fused_offset_decoder_loads_a_reference_shaped_state_dict():
                       "bw_linears.1.bias": (128,), "bw_linears.2.weight": (128, 128, 1), "bw_linears.2.bias": (128,),
                       "bw_linears.3.weight": (128, 191, 1), "bw_linears.3.bias": (128,), "bw_fc.weight": (24, 128, 1),
                       "bw_fc.bias": (24,)}
+
+
+def test_render_with_the_fused_offset_network_equals_render_with_its_torch_ops():
+    """render() with motion_offset_flag on (gaussian_renderer/__init__.py:100-106: lbs_weights = pc.lweight_offset_decoder(means3D)):
+    the network on the fused kernels against the same module in torch ops -- same images, same gradients of the network's and the
+    model's parameters."""
+    import types
+    from mygauhuman_amd import human_synth
+    from mygauhuman_amd.gaussian_renderer import render
+    res = {}
+    for fused in (True, False):
+        model, body = human_synth.build(6000, 1500, "cuda", seed=3, motion=True, decoder="reference_size")
+        model.lweight_offset_decoder.use_fused = fused
+        cam = human_synth.view_camera(body, 160, 128, 0, n_views=8, device="cuda")
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True)
+        o = render(1, cam, model, pipe, torch.zeros(3, device="cuda"))
+        (o["render"].mean() + 0.5 * o["render_alpha"].mean() + o["normal"].mean()).backward()
+        net = list(model.lweight_offset_decoder.parameters())
+        assert all(p.grad is not None for p in net)
+        res[fused] = ([o[k].detach() for k in ("render", "render_alpha", "normal")],
+                      [p.grad.clone() for p in net] + [p.grad.clone() for p in model.parameters() if p.grad is not None])
+    for a, b in zip(res[True][0], res[False][0]):
+        assert float((a - b).abs().max()) <= 2e-5
+    for a, b in zip(res[True][1], res[False][1]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-12, float((a - b).abs().max()) / max(scale, 1e-30)

@@ -4,6 +4,8 @@ validation of the operator API mirrors the reference, and the product path refus
 import os
 import re
 
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -117,6 +119,19 @@ def test_dropin_registers_the_renderer_for_train_py():
     network_gui.init("127.0.0.1", 6009)
     import inspect
     assert list(inspect.signature(render).parameters)[:5] == ["iteration", "viewpoint_camera", "pc", "pipe", "bg_color"]
+
+
+def test_dropin_registers_the_skinning_offset_network():
+    """scene/gaussian_model.py:27,99: `from nets.mlp_delta_weight_lbs import LBSOffsetDecoder`; LBSOffsetDecoder(total_bones=24); its
+    state_dict travels in the checkpoints (keys bw_linears.N.{weight,bias}, bw_fc.{weight,bias}: nets/mlp_delta_weight_lbs.py:17-22)."""
+    import types
+    import mygauhuman_amd
+    sys.modules.setdefault("nets", types.ModuleType("nets"))   # (the reference's package when its tree is on the path)
+    mygauhuman_amd.install_dropin(nets=True)
+    from nets.mlp_delta_weight_lbs import LBSOffsetDecoder
+    dec = LBSOffsetDecoder(total_bones=24)
+    assert sorted(dec.state_dict()) == sorted([f"bw_linears.{i}.{k}" for i in range(4) for k in ("weight", "bias")] + ["bw_fc.weight", "bw_fc.bias"])
+    assert tuple(dec.bw_linears[3].weight.shape) == (128, 191, 1) and tuple(dec.bw_fc.weight.shape) == (24, 128, 1)
 
 
 def test_synthetic_scene_is_reproducible():
