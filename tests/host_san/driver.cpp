@@ -319,12 +319,46 @@ static void threaded() {
   EXPECT(gsr_set_tuning("tile_order", 1) == GSR_OK);
 }
 
+// the skinning-offset network's entry points (csrc/mlp.hip): argument checks and launch geometries, host layer only
+static void offset_network() {
+  const size_t n = gsr_lbs_offset_mlp_packed_floats();
+  EXPECT(n > 0 && n % 4 == 0);
+  std::vector<float> packed(n + 4), xyz(3 * 1000), out(24 * 1000), dout(24 * 1000);
+  float *pk = packed.data();
+  while (reinterpret_cast<uintptr_t>(pk) % 16) pk++;
+  const size_t shape_w[5] = {128 * 63, 128 * 128, 128 * 128, 128 * 191, 24 * 128}, shape_b[5] = {128, 128, 128, 128, 24};
+  std::vector<std::vector<float>> w(5), b(5), dw(5), db(5);
+  const float *wp[5], *bp[5];
+  float *dwp[5], *dbp[5];
+  for (int l = 0; l < 5; l++) {
+    w[l].assign(shape_w[l], 0.f), b[l].assign(shape_b[l], 0.f), dw[l].assign(shape_w[l], 0.f), db[l].assign(shape_b[l], 0.f);
+    wp[l] = w[l].data(), bp[l] = b[l].data(), dwp[l] = dw[l].data(), dbp[l] = db[l].data();
+  }
+  EXPECT(gsr_lbs_offset_mlp_pack(wp, bp, pk, nullptr) == GSR_OK);
+  EXPECT(gsr_lbs_offset_mlp_pack(nullptr, bp, pk, nullptr) == GSR_EINVAL);
+  const float *hole[5] = {wp[0], wp[1], nullptr, wp[3], wp[4]};
+  EXPECT(gsr_lbs_offset_mlp_pack(hole, bp, pk, nullptr) == GSR_EINVAL && strstr(gsr_last_error(), "layer 2") != nullptr);
+  for (int P : {0, 1, 255, 256, 257, 1000}) EXPECT(gsr_lbs_offset_mlp_forward(P, xyz.data(), pk, out.data(), nullptr) == GSR_OK);
+  EXPECT(gsr_lbs_offset_mlp_forward(-1, xyz.data(), pk, out.data(), nullptr) == GSR_EINVAL);
+  EXPECT(gsr_lbs_offset_mlp_forward(10, xyz.data(), pk + 1, out.data(), nullptr) == GSR_EINVAL);   // misaligned fragments
+  EXPECT(gsr_lbs_offset_mlp_forward(10, nullptr, pk, out.data(), nullptr) == GSR_EINVAL);
+  EXPECT(gsr_lbs_offset_mlp_backward_workspace_floats(1000) == (size_t)1120 * 1024 && gsr_lbs_offset_mlp_backward_workspace_floats(0) == 0);
+  std::vector<float> ws(gsr_lbs_offset_mlp_backward_workspace_floats(1000) + 4);
+  float *wsp = ws.data();
+  while (reinterpret_cast<uintptr_t>(wsp) % 16) wsp++;
+  for (int P : {0, 1, 1000}) EXPECT(gsr_lbs_offset_mlp_backward(P, xyz.data(), pk, dout.data(), wsp, dwp, dbp, nullptr) == GSR_OK);
+  EXPECT(gsr_lbs_offset_mlp_backward(10, xyz.data(), pk, dout.data(), wsp + 1, dwp, dbp, nullptr) == GSR_EINVAL);
+  float *dhole[5] = {dwp[0], nullptr, dwp[2], dwp[3], dwp[4]};
+  EXPECT(gsr_lbs_offset_mlp_backward(10, xyz.data(), pk, dout.data(), wsp, dhole, dbp, nullptr) == GSR_EINVAL);
+}
+
 int main(int argc, char **argv) {
   const bool threads_only = argc > 1 && !strcmp(argv[1], "threads");
   if (!threads_only) {
     check_carving();
     error_paths();
     single_thread_sweep();
+    offset_network();
   }
   threaded();
   if (hipstub_bad_launches()) {

@@ -78,6 +78,7 @@ hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t attr, int) {
   *v = attr == hipDeviceAttributeMultiprocessorCount ? 256 : 64;
   return hipSuccess;
 }
+hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) {
   *p = malloc(n ? n : 1);
   return *p ? hipSuccess : hipErrorOutOfMemory;
