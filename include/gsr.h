@@ -595,6 +595,13 @@ int gsr_frame_attributes_backward_acc(int P, int sh_degree, int M, const float *
 size_t gsr_lbs_offset_mlp_packed_floats(void);
 int gsr_lbs_offset_mlp_pack(const float *const *weights, const float *const *biases, float *packed, gsr_stream_t stream);
 int gsr_lbs_offset_mlp_forward(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream);
+/* Which matrix instruction the forward and the backward's chain run on (process-wide): 1 (default) = v_mfma_f32_32x32x16_bf16 with BOTH
+ * operands split in two bf16 terms, three products per step (error 2^-16 of a product: 7e-6 of the output's scale against float64,
+ * 16 x the rate of the f32 instruction); 0 = v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, 6e-7). The weight-gradient products
+ * always run on the f32 instruction. */
+int gsr_lbs_offset_mlp_set_precision(int mode);
+/* The forward on the bf16 instruction whatever the mode (comparisons: tools/mlp_bench.py). */
+int gsr_debug_lbs_offset_mlp_forward_bf16x3(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream);
 /* Backward w.r.t. the parameters (the positions arrive detached, gaussian_renderer/__init__.py:104: no input gradient).  The forward
  * is run again inside (no activation was kept), dL_dout is [P][24]; the gradients are ADDED into dL_dweights[5] / dL_dbiases[5] (host
  * arrays of device pointers, the module's own layouts: zero them first); workspace: gsr_lbs_offset_mlp_backward_workspace_floats(P)

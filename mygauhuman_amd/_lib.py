@@ -30,7 +30,7 @@ SYMBOLS = [
     "gsr_geometry_bytes", "gsr_image_bytes", "gsr_binning_bytes", "gsr_rasterize_forward_async",
     "gsr_alpha_mask_loss_backward", "gsr_phase1_loss_partials", "gsr_phase1_loss_forward", "gsr_rasterize_backward_phase1_loss", "gsr_rasterize_backward_alpha_mask_loss", "gsr_rasterize_forward_ex", "gsr_rasterize_forward_async_ex", "gsr_rasterize_backward_ex",
     "gsr_dist2_workspace_bytes", "gsr_dist2", "gsr_sort_workspace_bytes", "gsr_sort_pairs_u64",
-    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_backward_workgroups", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_lbs_forward_cached", "gsr_lbs_nn_cache_bytes", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_sh_view_pack_posed", "gsr_sh_grad_from_views_posed", "gsr_step_status", "gsr_step_finish", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_model_activations_forward", "gsr_model_activations_backward", "gsr_frame_attributes_forward_split", "gsr_frame_attributes_backward_split", "gsr_frame_attributes_backward_acc", "gsr_model_activations_backward_acc", "gsr_lbs_offset_mlp_packed_floats", "gsr_lbs_offset_mlp_pack", "gsr_lbs_offset_mlp_forward", "gsr_lbs_offset_mlp_backward_workspace_floats", "gsr_lbs_offset_mlp_backward",
+    "gsr_sort_pairs_u32", "gsr_lbs_forward", "gsr_lbs_backward", "gsr_lbs_backward_workgroups", "gsr_lbs_workspace_bytes", "gsr_lbs_grid_build", "gsr_lbs_forward_grid", "gsr_lbs_forward_cached", "gsr_lbs_nn_cache_bytes", "gsr_smpl_pose_forward", "gsr_smpl_pose_backward", "gsr_sh_view_pack", "gsr_sh_grad_from_views", "gsr_sh_view_pack_posed", "gsr_sh_grad_from_views_posed", "gsr_step_status", "gsr_step_finish", "gsr_knn_self", "gsr_knn_nearest", "gsr_gather_rows", "gsr_ssim_forward", "gsr_ssim_backward", "gsr_gemv_rows", "gsr_gemv_rows_t", "gsr_frame_attributes_forward", "gsr_frame_attributes_backward", "gsr_model_activations_forward", "gsr_model_activations_backward", "gsr_frame_attributes_forward_split", "gsr_frame_attributes_backward_split", "gsr_frame_attributes_backward_acc", "gsr_model_activations_backward_acc", "gsr_lbs_offset_mlp_packed_floats", "gsr_lbs_offset_mlp_pack", "gsr_lbs_offset_mlp_forward", "gsr_lbs_offset_mlp_backward_workspace_floats", "gsr_lbs_offset_mlp_backward", "gsr_debug_lbs_offset_mlp_forward_bf16x3", "gsr_lbs_offset_mlp_set_precision",
 ]
 
 GSR_OK = 0
@@ -163,6 +163,10 @@ def _load():
     lib.gsr_lbs_offset_mlp_pack.restype = C.c_int
     lib.gsr_lbs_offset_mlp_forward.argtypes = [C.c_int, fp, fp, fp, vp]
     lib.gsr_lbs_offset_mlp_forward.restype = C.c_int
+    lib.gsr_debug_lbs_offset_mlp_forward_bf16x3.argtypes = [C.c_int, fp, fp, fp, vp]
+    lib.gsr_debug_lbs_offset_mlp_forward_bf16x3.restype = C.c_int
+    lib.gsr_lbs_offset_mlp_set_precision.argtypes = [C.c_int]
+    lib.gsr_lbs_offset_mlp_set_precision.restype = C.c_int
     lib.gsr_lbs_offset_mlp_backward_workspace_floats.argtypes = [C.c_int]
     lib.gsr_lbs_offset_mlp_backward_workspace_floats.restype = C.c_size_t
     lib.gsr_lbs_offset_mlp_backward.argtypes = [C.c_int, fp, fp, fp, fp, C.POINTER(fp), C.POINTER(fp), vp]

@@ -17,6 +17,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "gsr_common.h"
 
 namespace gsr {
@@ -53,8 +55,18 @@ __host__ __device__ constexpr int mlp_bwd_offset(int s) {
   return o;
 }
 constexpr int MLP_PACKED_ALL = mlp_bwd_offset(4);
+// bf16 fragments ("bf16x3": every weight as two bf16 terms, hi + lo), the same float counts and offsets as the f32 fragments:
+// 16-byte units [input tile][k-step 0..1][output tile][hi | lo][lane], eight bf16 each
+constexpr int MLP_PACKED_FWD16 = MLP_PACKED_ALL;                                  // bf16 forward fragments
+constexpr int MLP_PACKED_BWD16 = MLP_PACKED_FWD16 + MLP_PACKED_W;                 // bf16 backward fragments (steps fc, 3, 2, 1)
+constexpr int MLP_PACKED_TOTAL = MLP_PACKED_BWD16 + (MLP_PACKED_ALL - MLP_PACKED);
 
 __host__ __device__ constexpr int mlp_row_of_reg(int i) { return (i & 3) + 8 * (i >> 2); }
+
+__host__ __device__ __forceinline__ uint32_t bf16_rne(float x) {   // round to nearest even (finite inputs)
+  uint32_t u = __builtin_bit_cast(uint32_t, x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
 
 struct MlpWeights {   // the reference module's tensors (Conv1d weight [out][in][1] = row-major [out][in])
   const float *w[MLP_LAYERS];
@@ -64,7 +76,64 @@ struct MlpWeights {   // the reference module's tensors (Conv1d weight [out][in]
 // one thread per packed float
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpWeights src, float *packed) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= MLP_PACKED_ALL) return;
+  if (e >= MLP_PACKED_TOTAL) return;
+  if (e >= MLP_PACKED_BWD16) {   // backward fragments in bf16: W_l[o = the k of the step][column of input feature kf]
+    const int r0 = e - MLP_PACKED_BWD16 + MLP_PACKED;
+    int st = 0, base = MLP_PACKED;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (r0 >= mlp_bwd_offset(k)) {
+        st = k;
+        base = mlp_bwd_offset(k);
+      }
+    }
+    const int l = 4 - st, r = r0 - base, unit = r / 4, sub = r % 4;
+    const int lane = unit % 64, hl = (unit / 64) % 2, t_out = (unit / 128) % 4, ks = (unit / 512) % 2, t_in = unit / 1024;
+    const int kf = 32 * t_out + (lane & 31), ncols = l == 3 ? MLP_E + MLP_W : MLP_W, col = l == 3 ? MLP_E + kf : kf;
+    const int nrows = l == 4 ? MLP_OUT : MLP_W;
+    uint32_t word = 0;
+    for (int q = 0; q < 2; q++) {
+      const int j = 2 * sub + q;
+      const int o = 32 * t_in + 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+      const float w = o < nrows ? src.w[l][(size_t)o * ncols + col] : 0.f;
+      const uint32_t hi = bf16_rne(w), lo = bf16_rne(w - __uint_as_float(hi << 16));
+      word |= (hl ? lo : hi) << (16 * q);
+    }
+    reinterpret_cast<uint32_t *>(packed)[e] = word;
+    return;
+  }
+  if (e >= MLP_PACKED_ALL) {   // two bf16 elements (2 sub, 2 sub + 1) of a 16-byte fragment unit
+    const int r0 = e - MLP_PACKED_ALL;
+    int l = 0, base = 0;
+#pragma unroll
+    for (int k = 0; k < MLP_LAYERS; k++) {
+      if (r0 >= mlp_packed_offset(k)) {
+        l = k;
+        base = mlp_packed_offset(k);
+      }
+    }
+    const int nto = mlp_tout(l), r = r0 - base, unit = r / 4, sub = r % 4;
+    const int lane = unit % 64, hl = (unit / 64) % 2, t_out = (unit / 128) % nto, ks = (unit / 128 / nto) % 2, t_in = unit / 128 / nto / 2;
+    const int o = 32 * t_out + (lane & 31), nrows = l == 4 ? MLP_OUT : MLP_W;
+    uint32_t word = 0;
+    for (int q = 0; q < 2; q++) {
+      const int j = 2 * sub + q;
+      const int k = 32 * t_in + 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+      int col, ncols;
+      if (l == 0) {
+        ncols = MLP_E, col = k < MLP_E ? k : -1;
+      } else if (l == 3) {
+        ncols = MLP_E + MLP_W, col = k < MLP_E ? k : (k == MLP_E ? -1 : MLP_E + (k - 64));
+      } else {
+        ncols = MLP_W, col = k;
+      }
+      const float w = (col >= 0 && o < nrows) ? src.w[l][(size_t)o * ncols + col] : 0.f;
+      const uint32_t hi = bf16_rne(w), lo = bf16_rne(w - __uint_as_float(hi << 16));
+      word |= (hl ? lo : hi) << (16 * q);
+    }
+    reinterpret_cast<uint32_t *>(packed)[e] = word;
+    return;
+  }
   if (e >= MLP_PACKED) {   // backward fragments: W_l[o][column of input feature k]
     int st = 0, base = MLP_PACKED;
 #pragma unroll
@@ -239,6 +308,144 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT "bf16x3": the same forward on v_mfma_f32_32x32x16_bf16 (8 passes for K = 16 against 16 passes for K = 2 of the f32
+// instruction: 16 x the rate) with f32-like accuracy from splitting BOTH operands in two bf16 terms, x = hi + lo, and three products
+// per step (hi hi + hi lo + lo hi; the dropped lo lo is 2^-16 of the product).  An activation tile converts in place: registers
+// 8 s .. 8 s + 7 of the accumulator ARE the B fragment of k-step s (their rows 16 s + 8 (j >> 2) + 4 half + (j & 3), j = 0..7; the
+// weights are packed in that k order).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void mlp_split8(const f32x16 &t, int s, uint4 &hi, uint4 &lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float x0 = t[8 * s + 2 * q], x1 = t[8 * s + 2 * q + 1];
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h[q]) : "v"(x0), "v"(x1));
+    const float r0 = x0 - __uint_as_float(h[q] << 16), r1 = x1 - __uint_as_float(h[q] & 0xFFFF0000u);
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l[q]) : "v"(r0), "v"(r1));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+template <int NT>
+__device__ __forceinline__ void mlp_split_tiles(const f32x16 (&t)[NT], uint4 (&fh)[NT][2], uint4 (&fl)[NT][2]) {
+#pragma unroll
+  for (int k = 0; k < NT; k++) {
+    mlp_split8(t[k], 0, fh[k][0], fl[k][0]);
+    mlp_split8(t[k], 1, fh[k][1], fl[k][1]);
+  }
+}
+
+template <int NTI, int NTO>
+__device__ __forceinline__ void mlp_mm_bf16(const uint4 *s_w, const uint4 (&fh)[NTI][2], const uint4 (&fl)[NTI][2], f32x16 (&out)[NTO],
+                                            uint32_t lane) {
+#pragma unroll
+  for (int ti = 0; ti < NTI; ti++) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, fh[ti][ks]), bl = __builtin_bit_cast(bf16x8, fl[ti][ks]);
+#pragma unroll
+      for (int to = 0; to < NTO; to++) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, s_w[(((ti * 2 + ks) * NTO + to) * 2 + 0) * 64 + lane]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, s_w[(((ti * 2 + ks) * NTO + to) * 2 + 1) * 64 + lane]);
+        out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, out[to], 0, 0, 0);   // (the small terms first)
+        out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, out[to], 0, 0, 0);
+        out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, out[to], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int L, int NIN>
+__device__ __forceinline__ void mlp_layer_bf16(const uint4 *s_w, const float *bias, const uint4 (&fh)[NIN][2], const uint4 (&fl)[NIN][2],
+                                               f32x16 (&out)[mlp_tout(L)], uint32_t lane) {
+  constexpr int NTO = mlp_tout(L);
+  static_assert(NIN == mlp_tin(L), "input tiles of the layer");
+  const uint32_t half = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NTO; t++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[t][i] = bias[32 * t + mlp_row_of_reg(i) + 4 * half];
+  }
+  mlp_mm_bf16<NIN, NTO>(s_w, fh, fl, out, lane);
+}
+
+template <int L>
+__device__ __forceinline__ void mlp_stage_bf16(const float *packed, float *s_w) {
+  mlp_stage_block<MLP_PACKED_ALL + mlp_packed_offset(L), mlp_packed_floats(L)>(packed, s_w);
+}
+
+__global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_forward_bf16x3_kernel(int P, const float *xyz,
+                                                                                                          const float *packed, float *out) {
+  extern __shared__ __attribute__((aligned(16))) float s_mlp[];
+  float *s_w = s_mlp, *s_b = s_mlp + MLP_LDS_FLOATS;
+  const uint4 *s_f = reinterpret_cast<const uint4 *>(s_w);
+  const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, half = lane >> 5;
+  const int p = (int)(blockIdx.x * (uint32_t)MLP_WG_POINTS + wave * 32u + (lane & 31u));
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (p < P) {
+    x = xyz[(size_t)p * 3 + 0];
+    y = xyz[(size_t)p * 3 + 1];
+    z = xyz[(size_t)p * 3 + 2];
+  }
+  for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
+  mlp_stage_bf16<0>(packed, s_w);
+  uint4 eh[2][2], el[2][2];
+  {
+    f32x16 emb[2];
+    mlp_embed_tiles(emb, (int)half, x, y, z);
+    mlp_split_tiles<2>(emb, eh, el);
+  }
+  __syncthreads();
+  f32x16 a[4];
+  uint4 fh[4][2], fl[4][2];
+  mlp_layer_bf16<0, 2>(s_f, s_b, eh, el, a, lane);
+  mlp_relu(a);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bf16<1>(packed, s_w);
+  __syncthreads();
+  mlp_layer_bf16<1, 4>(s_f, s_b + MLP_W, fh, fl, a, lane);
+  mlp_relu(a);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bf16<2>(packed, s_w);
+  __syncthreads();
+  mlp_layer_bf16<2, 4>(s_f, s_b + 2 * MLP_W, fh, fl, a, lane);
+  mlp_relu(a);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bf16<3>(packed, s_w);
+  __syncthreads();
+  {
+    uint4 ch[6][2], cl[6][2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        ch[k][q] = k < 2 ? eh[k][q] : fh[k - 2][q];
+        cl[k][q] = k < 2 ? el[k][q] : fl[k - 2][q];
+      }
+    }
+    mlp_layer_bf16<3, 6>(s_f, s_b + 3 * MLP_W, ch, cl, a, lane);
+  }
+  mlp_relu(a);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bf16<4>(packed, s_w);
+  __syncthreads();
+  f32x16 o[1];
+  mlp_layer_bf16<4, 4>(s_f, s_b + 4 * MLP_W, fh, fl, o, lane);
+  if (p < P) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = mlp_row_of_reg(i) + 4 * (int)half;
+      if (row < MLP_OUT) out[(size_t)p * MLP_OUT + row] = o[0][i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Backward.  Two kernels:
 //   chain : per 32 points of a wave, the forward again (no activation was kept) -- every layer's output is written feature-major
 //           ([feature][point]: the lanes of a tile are consecutive points, so the stores coalesce) for the weight gradients and its
@@ -370,6 +577,120 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0, b, p, half);
 }
 
+// the chain kernel on the bf16 instruction (both operands split in two bf16 terms, see mlp_forward_bf16x3_kernel): what the module runs
+template <int ST>
+__device__ __forceinline__ void mlp_stage_bwd16(const float *packed, float *s_w) {
+  mlp_stage_block<MLP_PACKED_BWD16 + (mlp_bwd_offset(ST) - MLP_PACKED), mlp_bwd_floats(ST)>(packed, s_w);
+}
+
+__global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_backward_chain_bf16x3_kernel(
+    int P, int Pp_, const float *xyz, const float *packed, const float *dout, float *ws) {
+  extern __shared__ __attribute__((aligned(16))) float s_mlp[];
+  float *s_w = s_mlp, *s_b = s_mlp + MLP_LDS_FLOATS;
+  const uint4 *s_f = reinterpret_cast<const uint4 *>(s_w);
+  const size_t Pp = (size_t)Pp_;
+  const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, half = lane >> 5;
+  const int p = (int)(blockIdx.x * (uint32_t)MLP_WG_POINTS + wave * 32u + (lane & 31u));   // < Pp always
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (p < P) {
+    x = xyz[(size_t)p * 3 + 0];
+    y = xyz[(size_t)p * 3 + 1];
+    z = xyz[(size_t)p * 3 + 2];
+  }
+  for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
+  mlp_stage_bf16<0>(packed, s_w);
+  uint4 eh[2][2], el[2][2];
+  {
+    f32x16 emb[2];
+    mlp_embed_tiles(emb, (int)half, x, y, z);
+    mlp_store_tiles<2>(ws, Pp, MLP_WS_EMB, emb, p, half);
+    mlp_split_tiles<2>(emb, eh, el);
+  }
+  __syncthreads();
+  // ---- the forward again: outputs to the workspace, masks to registers
+  f32x16 a[4];
+  uint4 fh[4][2], fl[4][2];
+  uint32_t m1[2], m2[2], m3[2], m4[2];
+  mlp_layer_bf16<0, 2>(s_f, s_b, eh, el, a, lane);
+  mlp_relu_mask(a, m1);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H1, a, p, half);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bf16<1>(packed, s_w);
+  __syncthreads();
+  mlp_layer_bf16<1, 4>(s_f, s_b + MLP_W, fh, fl, a, lane);
+  mlp_relu_mask(a, m2);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H1 + MLP_W, a, p, half);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bf16<2>(packed, s_w);
+  __syncthreads();
+  mlp_layer_bf16<2, 4>(s_f, s_b + 2 * MLP_W, fh, fl, a, lane);
+  mlp_relu_mask(a, m3);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H1 + 2 * MLP_W, a, p, half);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bf16<3>(packed, s_w);
+  __syncthreads();
+  {
+    uint4 ch[6][2], cl[6][2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        ch[k][q] = k < 2 ? eh[k][q] : fh[k - 2][q];
+        cl[k][q] = k < 2 ? el[k][q] : fl[k - 2][q];
+      }
+    }
+    mlp_layer_bf16<3, 6>(s_f, s_b + 3 * MLP_W, ch, cl, a, lane);
+  }
+  mlp_relu_mask(a, m4);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_H4, a, p, half);
+  // ---- backward: dOut -> dh4 -> dZ3 -> dh3 -> dZ2 -> dh2 -> dZ1 -> dh1 -> dZ0
+  uint4 dh[1][2], dl[1][2];
+  {
+    f32x16 d[1];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = mlp_row_of_reg(i) + 4 * (int)half;
+      d[0][i] = (row < MLP_OUT && p < P) ? dout[(size_t)p * MLP_OUT + row] : 0.f;
+    }
+    mlp_store_tiles<1>(ws, Pp, MLP_WS_DOUT, d, p, half);
+    mlp_split_tiles<1>(d, dh, dl);
+  }
+  __syncthreads();
+  mlp_stage_bwd16<0>(packed, s_w);
+  __syncthreads();
+  mlp_zero(a);
+  mlp_mm_bf16<1, 4>(s_f, dh, dl, a, lane);
+  mlp_apply_mask(a, m4);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + 3 * MLP_W, a, p, half);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bwd16<1>(packed, s_w);
+  __syncthreads();
+  mlp_zero(a);
+  mlp_mm_bf16<4, 4>(s_f, fh, fl, a, lane);
+  mlp_apply_mask(a, m3);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + 2 * MLP_W, a, p, half);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bwd16<2>(packed, s_w);
+  __syncthreads();
+  mlp_zero(a);
+  mlp_mm_bf16<4, 4>(s_f, fh, fl, a, lane);
+  mlp_apply_mask(a, m2);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + MLP_W, a, p, half);
+  mlp_split_tiles<4>(a, fh, fl);
+  __syncthreads();
+  mlp_stage_bwd16<3>(packed, s_w);
+  __syncthreads();
+  mlp_zero(a);
+  mlp_mm_bf16<4, 4>(s_f, fh, fl, a, lane);
+  mlp_apply_mask(a, m1);
+  mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0, a, p, half);
+}
+
 struct MlpWgradLayer {
   int a_row, ta;            // dZ rows in the workspace, tiles of 32
   int b_row0, tb0, b_row1;  // X rows: tb0 tiles from b_row0, the rest from b_row1
@@ -482,9 +803,11 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const MlpWgradArgs a) {
 
 }  // namespace gsr
 
+static std::atomic<int> g_mlp_precision{1};   // 0: f32 MFMA, 1: bf16 MFMA with both operands split in two terms (default)
+
 extern "C" {
 
-size_t gsr_lbs_offset_mlp_packed_floats(void) { return (size_t)gsr::MLP_PACKED_ALL; }
+size_t gsr_lbs_offset_mlp_packed_floats(void) { return (size_t)gsr::MLP_PACKED_TOTAL; }
 
 size_t gsr_lbs_offset_mlp_backward_workspace_floats(int P) {
   const size_t Pp = ((size_t)(P > 0 ? P : 0) + gsr::MLP_WG_POINTS - 1) / gsr::MLP_WG_POINTS * gsr::MLP_WG_POINTS;
@@ -514,8 +837,14 @@ int gsr_lbs_offset_mlp_backward(int P, const float *xyz, const float *packed, co
   constexpr size_t lds = (size_t)(MLP_LDS_FLOATS + MLP_PACKED_B) * sizeof(float);
   GSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
-  hipLaunchKernelGGL(mlp_backward_chain_kernel, dim3((unsigned)(Pp / MLP_WG_POINTS)), dim3(MLP_WG), lds, stream, P, Pp, xyz, packed, dL_dout,
-                     workspace);
+  GSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_backward_chain_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  if (g_mlp_precision.load() == 1)
+    hipLaunchKernelGGL(mlp_backward_chain_bf16x3_kernel, dim3((unsigned)(Pp / MLP_WG_POINTS)), dim3(MLP_WG), lds, stream, P, Pp, xyz, packed,
+                       dL_dout, workspace);
+  else
+    hipLaunchKernelGGL(mlp_backward_chain_kernel, dim3((unsigned)(Pp / MLP_WG_POINTS)), dim3(MLP_WG), lds, stream, P, Pp, xyz, packed, dL_dout,
+                       workspace);
   GSR_HIP(hipGetLastError());
   MlpWgradArgs a;
   memset(&a, 0, sizeof(a));
@@ -555,8 +884,32 @@ int gsr_lbs_offset_mlp_pack(const float *const *weights, const float *const *bia
     w.b[l] = biases[l];
   }
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3((MLP_PACKED_ALL + 255) / 256), dim3(256), 0, stream, w, packed);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3((MLP_PACKED_TOTAL + 255) / 256), dim3(256), 0, stream, w, packed);
   return check_hip(hipGetLastError(), "mlp_pack_kernel", __FILE__, __LINE__);
+}
+
+int gsr_lbs_offset_mlp_set_precision(int mode) {
+  if (mode != 0 && mode != 1) {
+    gsr::set_error("gsr_lbs_offset_mlp_set_precision: 0 (f32 matrix instruction) or 1 (bf16 instruction, operands split in two terms)");
+    return GSR_EINVAL;
+  }
+  g_mlp_precision.store(mode);
+  return GSR_OK;
+}
+
+int gsr_debug_lbs_offset_mlp_forward_bf16x3(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream_) {
+  using namespace gsr;
+  if (P < 0 || (P > 0 && (!xyz || !packed || !out)) || reinterpret_cast<size_t>(packed) % 16 != 0) {
+    set_error("gsr_debug_lbs_offset_mlp_forward_bf16x3: bad size, null pointer or misaligned fragments");
+    return GSR_EINVAL;
+  }
+  if (P == 0) return GSR_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  constexpr size_t lds = (size_t)(MLP_LDS_FLOATS + MLP_PACKED_B) * sizeof(float);
+  GSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mlp_forward_bf16x3_kernel, dim3((unsigned)((P + MLP_WG_POINTS - 1) / MLP_WG_POINTS)), dim3(MLP_WG), lds, stream, P, xyz,
+                     packed, out);
+  return check_hip(hipGetLastError(), "mlp_forward_bf16x3_kernel", __FILE__, __LINE__);
 }
 
 int gsr_lbs_offset_mlp_forward(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream_) {
@@ -575,6 +928,7 @@ int gsr_lbs_offset_mlp_forward(int P, const float *xyz, const float *packed, flo
   static_assert(lds <= 160 * 1024, "one layer's packed weights fit the LDS of a CU");
   // (dynamic LDS above 64 KB needs the attribute; set per call: it is per device and costs nothing)
   GSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (g_mlp_precision.load() == 1) return gsr_debug_lbs_offset_mlp_forward_bf16x3(P, xyz, packed, out, stream_);
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((P + MLP_WG_POINTS - 1) / MLP_WG_POINTS)), dim3(MLP_WG), lds, stream, P, xyz, packed,
                      out);
   return check_hip(hipGetLastError(), "mlp_forward_kernel", __FILE__, __LINE__);

@@ -20,6 +20,12 @@ from ._lib import check, lib, ptr
 _OCTAVES = 10
 
 
+def set_precision(mode):
+    """"bf16x3" (default: the bf16 matrix instruction with both operands split in two bf16 terms -- 7e-6 of the output's scale against
+    float64, 2.7 x the speed) or "f32" (the f32 matrix instruction, 6e-7) for the forward and the backward's chain; process-wide."""
+    check(lib.gsr_lbs_offset_mlp_set_precision({"f32": 0, "bf16x3": 1}[mode]), "gsr_lbs_offset_mlp_set_precision")
+
+
 def positional_embedding(x):
     """[P, 3] -> [P, 63]: (x, sin(2^o x), cos(2^o x), o = 0..9) in the order of get_embedder(10) (nets/mlp_delta_weight_lbs.py:34-77)."""
     freqs = 2.0 ** torch.arange(_OCTAVES, dtype=x.dtype, device=x.device)
