@@ -595,10 +595,9 @@ int gsr_frame_attributes_backward_acc(int P, int sh_degree, int M, const float *
 size_t gsr_lbs_offset_mlp_packed_floats(void);
 int gsr_lbs_offset_mlp_pack(const float *const *weights, const float *const *biases, float *packed, gsr_stream_t stream);
 int gsr_lbs_offset_mlp_forward(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream);
-/* Which matrix instruction the forward and the backward's chain run on (process-wide): 1 (default) = v_mfma_f32_32x32x16_bf16 with BOTH
+/* Which matrix instruction the three kernels run on (process-wide): 1 (default) = v_mfma_f32_32x32x16_bf16 with BOTH
  * operands split in two bf16 terms, three products per step (error 2^-16 of a product: 7e-6 of the output's scale against float64,
- * 16 x the rate of the f32 instruction); 0 = v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, 6e-7). The weight-gradient products
- * always run on the f32 instruction. */
+ * 16 x the rate of the f32 instruction); 0 = v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, 6e-7). */
 int gsr_lbs_offset_mlp_set_precision(int mode);
 /* The forward on the bf16 instruction whatever the mode (comparisons: tools/mlp_bench.py). */
 int gsr_debug_lbs_offset_mlp_forward_bf16x3(int P, const float *xyz, const float *packed, float *out, gsr_stream_t stream);

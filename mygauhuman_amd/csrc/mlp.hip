@@ -787,6 +787,123 @@ __device__ __forceinline__ void mlp_wgrad_body(const MlpWgradLayer &L, const flo
   if ((int)threadIdx.x < TA * 32 && (int)threadIdx.x < L.nrows) atomicAdd(&L.db[threadIdx.x], dbsum);
 }
 
+// the same products on the bf16 instruction: the staged rows are converted to two bf16 planes (hi, lo) on their way into LDS; a row
+// of 32 points = 64 bytes + 16 of padding (stride 80: the 16-byte fragment reads of a lane group fall on 16 distinct bank quads);
+// lane (r, h) of k-step s reads points 16 s + 8 h .. + 7 of row r -- one ds_read_b128 -- for A[i = o][kk = p] and B[kk = p][j = k] alike
+constexpr int WG16_STRIDE = 20;   // 32-bit words per staged row of 32 bf16
+
+template <int TA, int TB>
+__device__ __forceinline__ void mlp_wgrad_body_bf16(const MlpWgradLayer &L, const float *ws, size_t Pp, int p0, int p1, uint32_t *s_Ah,
+                                                    uint32_t *s_Al, uint32_t *s_Bh, uint32_t *s_Bl) {
+  constexpr int NACC = TA == 4 ? TB : 1;
+  const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE, half = lane >> 5, r = lane & 31u;
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[k][i] = 0.f;
+  }
+  const int my_ta = TA == 4 ? (int)wave : 0;
+  constexpr int NQ = ((TA + TB) * 32 * 8 + 255) / 256;   // 16-byte pieces per thread per stage
+  constexpr int NQA = (TA * 32 * 8 + 255) / 256;          // ... of which the first NQA belong to dZ rows (row = tid / 8 + 32 j)
+  float4 pre[NQ];
+  float dbpart[NQA];
+#pragma unroll
+  for (int j = 0; j < NQA; j++) dbpart[j] = 0.f;
+  auto fetch = [&](int pb) {
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+      const int q = (int)threadIdx.x + j * 256;
+      if (q < (TA + TB) * 32 * 8) {
+        const int row = q / 8, c4 = (q % 8) * 4, rb = row - TA * 32;
+        const int src_row = row < TA * 32 ? L.a_row + row : (rb < L.tb0 * 32 ? L.b_row0 + rb : L.b_row1 + (rb - L.tb0 * 32));
+        pre[j] = *reinterpret_cast<const float4 *>(&ws[(size_t)src_row * Pp + pb + c4]);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+      const int q = (int)threadIdx.x + j * 256;
+      if (q < (TA + TB) * 32 * 8) {
+        const int row = q / 8, c4 = (q % 8) * 4, rb = row - TA * 32;
+        const bool isA = row < TA * 32;
+        const float4 v = pre[j];
+        uint32_t h0, h1, l0, l1;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h0) : "v"(v.x), "v"(v.y));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h1) : "v"(v.z), "v"(v.w));
+        const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xFFFF0000u);
+        const float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xFFFF0000u);
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l0) : "v"(r0), "v"(r1));
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l1) : "v"(r2), "v"(r3));
+        const int w = (isA ? row : rb) * WG16_STRIDE + c4 / 2;
+        *reinterpret_cast<uint2 *>((isA ? s_Ah : s_Bh) + w) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>((isA ? s_Al : s_Bl) + w) = make_uint2(l0, l1);
+        if (j < NQA && isA) dbpart[j < NQA ? j : 0] += (v.x + v.y) + (v.z + v.w);
+      }
+    }
+  };
+  fetch(p0);
+  for (int pb = p0; pb < p1; pb += 32) {
+    commit();
+    __syncthreads();
+    if (pb + 32 < p1) fetch(pb + 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int fo = 8 * ks + 4 * (int)half;   // word offset of the lane's eight points inside a row
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(s_Ah + (32 * my_ta + (int)r) * WG16_STRIDE + fo));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(s_Al + (32 * my_ta + (int)r) * WG16_STRIDE + fo));
+#pragma unroll
+      for (int k = 0; k < NACC; k++) {
+        const int tb = TA == 4 ? k : (int)wave;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(s_Bh + (32 * tb + (int)r) * WG16_STRIDE + fo));
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(s_Bl + (32 * tb + (int)r) * WG16_STRIDE + fo));
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[k], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+    const int tb = TA == 4 ? k : (int)wave;
+    const int kf = 32 * tb + (int)r;
+    int col = kf;
+    if (L.kind == 3) col = kf < MLP_E ? kf : (kf == MLP_E ? -1 : MLP_E + (kf - 64));
+    if (col >= L.ncols) col = -1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int o = 32 * my_ta + mlp_row_of_reg(i) + 4 * (int)half;
+      if (col >= 0 && o < L.nrows) atomicAdd(&L.dW[(size_t)o * L.ncols + col], acc[k][i]);
+    }
+  }
+  // db[row]: the eight threads of a row (tid % 8) meet by shuffles; thread tid / 8 + 32 j owns dZ row tid / 8 + 32 j
+#pragma unroll
+  for (int j = 0; j < NQA; j++) {
+    float t = dbpart[j];
+    t += __shfl_xor(t, 1, WAVE);
+    t += __shfl_xor(t, 2, WAVE);
+    t += __shfl_xor(t, 4, WAVE);
+    const int row = (int)threadIdx.x / 8 + 32 * j;
+    if ((threadIdx.x & 7u) == 0u && row < TA * 32 && row < L.nrows) atomicAdd(&L.db[row], t);
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_wgrad_bf16x3_kernel(const MlpWgradArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_Ah[128 * WG16_STRIDE], s_Al[128 * WG16_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_Bh[192 * WG16_STRIDE], s_Bl[192 * WG16_STRIDE];
+  const MlpWgradLayer &L = a.L[blockIdx.y];
+  const int p0 = (int)blockIdx.x * a.chunk, p1 = min(a.Pp, p0 + a.chunk);
+  if (p0 >= p1) return;
+  switch (blockIdx.y) {
+    case 0: mlp_wgrad_body_bf16<4, 2>(L, a.ws, (size_t)a.Pp, p0, p1, s_Ah, s_Al, s_Bh, s_Bl); break;
+    case 3: mlp_wgrad_body_bf16<4, 6>(L, a.ws, (size_t)a.Pp, p0, p1, s_Ah, s_Al, s_Bh, s_Bl); break;
+    case 4: mlp_wgrad_body_bf16<1, 4>(L, a.ws, (size_t)a.Pp, p0, p1, s_Ah, s_Al, s_Bh, s_Bl); break;
+    default: mlp_wgrad_body_bf16<4, 4>(L, a.ws, (size_t)a.Pp, p0, p1, s_Ah, s_Al, s_Bh, s_Bl); break;
+  }
+}
+
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const MlpWgradArgs a) {
   __shared__ float s_A[128 * WG_STRIDE];
   __shared__ float s_B[192 * WG_STRIDE];
@@ -863,7 +980,10 @@ int gsr_lbs_offset_mlp_backward(int P, const float *xyz, const float *packed, co
     L.ncols = l == 0 ? MLP_E : (l == 3 ? MLP_E + MLP_W : MLP_W);
     L.kind = l == 3 ? 3 : 0;
   }
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)((Pp + a.chunk - 1) / a.chunk), MLP_LAYERS), dim3(256), 0, stream, a);
+  if (g_mlp_precision.load() == 1)
+    hipLaunchKernelGGL(mlp_wgrad_bf16x3_kernel, dim3((unsigned)((Pp + a.chunk - 1) / a.chunk), MLP_LAYERS), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)((Pp + a.chunk - 1) / a.chunk), MLP_LAYERS), dim3(256), 0, stream, a);
   return check_hip(hipGetLastError(), "mlp_wgrad_kernel", __FILE__, __LINE__);
 }
 
