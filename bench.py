@@ -275,7 +275,7 @@ def extra_workload(name, dev, steps=60, warmup=5):
 
 RENDER_WL = dict(P=200_000, V=6890, W=1024, H=1024, desc="render(): 200k articulated Gaussians (LBS -> attributes -> fused 21-channel "
                  "raster), 1024x1024, fwd+bwd, phase-1 training loss of train.py:261-265 (bound-masked L1 image / normal / axis + 0.1 L2 "
-                 "alpha); motion decoders off in the 1-GPU `extra` figure, stand-ins in --workload render")
+                 "alpha); motion decoders off in the `extra` figures `eager` / `one_graph`, on in `with_reference_sized_decoder*` and in --workload render")
 PHASE1_KEYS = ("render", "render_alpha", "normal", "render_axis")   # the images train.py:256-286 puts in the loss before the PBR phase
 
 
@@ -487,7 +487,10 @@ def main_render(a, rank, world, local, dev, rehearsal):
     from mygauhuman_amd import _lib, human_synth, parallel
     wl = RENDER_WL
     P = int(os.environ.get("GSR_BENCH_P", wl["P"]))
-    model, body = human_synth.build(P, wl["V"], dev, seed=0, motion=True)
+    # the skinning-offset network: the reference's layers on the fused MFMA kernels (nets.FusedLBSOffsetDecoder, random init);
+    # GSR_BENCH_DECODER=affine: rounds 3-4's 96-parameter stand-in, =reference_size_torch: the same network in torch ops
+    decoder = os.environ.get("GSR_BENCH_DECODER", "reference_size")
+    model, body = human_synth.build(P, wl["V"], dev, seed=0, motion=True, decoder=decoder)
     cam = human_synth.view_camera(body, wl["W"], wl["H"], rank, n_views=8, device=dev)
     bg = torch.zeros(3, device=dev)
     step = parallel.ViewParallelRender(model, _render_pipe(), bg)
@@ -526,9 +529,11 @@ def main_render(a, rank, world, local, dev, rehearsal):
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": wl["desc"] + f"; S-human seed 0, {world} ring view(s)/step, 1 view/rank, own pose per view; "
-                          "motion decoders = STAND-INS (a 69-128-69 pose MLP and an affine 96-parameter skinning-offset map), NOT the "
-                          "reference's nets/mlp_delta_*.py -- its per-Gaussian offset MLP (63-d embedding, 4 x 128 Conv1d, run every "
-                          "frame: gaussian_renderer/__init__.py:100-106) is outside the scoped path and its cost is NOT in this figure; "
+                          "motion_offset_flag on: a 69-128-69 pose MLP (stand-in for nets/mlp_delta_body_pose.py) and the per-Gaussian "
+                          "skinning-offset network with the layers of nets/mlp_delta_weight_lbs.py (63-d embedding, 63-128-128-128-(191)-"
+                          "128-24, random init, run every frame: gaussian_renderer/__init__.py:100-106) "
+                          + {"reference_size": "on the fused MFMA kernels of csrc/mlp.hip", "reference_size_torch": "in torch ops",
+                             "affine": "REPLACED by an affine 96-parameter stand-in (its cost is NOT in this figure)"}.get(decoder, decoder) + "; "
                           + ("REHEARSAL: all ranks on ONE device over gloo with host-staged collectives -- not a scaling number; "
                              if rehearsal else "") + f"exchange payload {step.payload_bytes / 1e6:.1f} MB/rank"
                           + (" (compact SH: all-gather + all-reduce)" if step.compact is not None else " (one all-reduce)"),
