@@ -292,7 +292,10 @@ __global__ __launch_bounds__(256) void nn_cache_update_kernel(int P, const float
     const float4 e = c.entry[p];
     const float dx = query[3 * (size_t)p] - e.x, dy = query[3 * (size_t)p + 1] - e.y, dz = query[3 * (size_t)p + 2] - e.z;
     const float d2 = dx * dx + dy * dy + dz * dz;
-    miss = !(e.w > 0.f && d2 < e.w * e.w);  // (NaN positions miss, like a negative rho)
+    // (NaN positions miss, like a negative rho = never searched.  A point that has not moved AT ALL keeps its id whatever the radius:
+    // entries whose two nearest vertices tie within rounding have rho = 0 and were searched again every frame -- in a loop over
+    // static points (render.py, evaluation) their serial searches were the whole 15 us of this kernel)
+    miss = !(e.w >= 0.f && (d2 == 0.f || d2 < e.w * e.w));
   }
   const uint64_t m = __ballot(miss);
   if (m != 0ull) {
