@@ -250,6 +250,32 @@ __device__ __forceinline__ void mlp_stage_block(const float *packed, float *s_w)
   float4 *dst = reinterpret_cast<float4 *>(s_w);
   for (int q = threadIdx.x; q < FLOATS / 4; q += MLP_WG) dst[q] = src[q];
 }
+// the same copy in two halves: the loads of the NEXT fragment block are issued before the current layer's MFMAs and land in LDS after
+// them (between the two barriers that used to enclose an exposed global round trip per layer: a quarter of the forward's time)
+constexpr int MLP_PRE = 3;   // x 16 floats per thread: the largest block is 24,576 floats / 512 threads = 48 floats
+// (kept as three 16-float vectors, like the activation tiles: a float4[12] array is left in scratch by the compiler)
+template <int OFFSET, int FLOATS, int NP>
+__device__ __forceinline__ void mlp_prefetch(const float *packed, f32x16 (&pre)[NP]) {
+  static_assert(FLOATS % (4 * MLP_WG) == 0 && FLOATS / (4 * MLP_WG) <= 4 * NP, "whole 16-byte pieces per thread");
+  const float4 *src = reinterpret_cast<const float4 *>(packed + OFFSET);
+#pragma unroll
+  for (int j = 0; j < FLOATS / (4 * MLP_WG); j++) {
+    const float4 t = src[(int)threadIdx.x + j * MLP_WG];
+    pre[j / 4][4 * (j % 4) + 0] = t.x;
+    pre[j / 4][4 * (j % 4) + 1] = t.y;
+    pre[j / 4][4 * (j % 4) + 2] = t.z;
+    pre[j / 4][4 * (j % 4) + 3] = t.w;
+  }
+}
+template <int FLOATS, int NP>
+__device__ __forceinline__ void mlp_commit(const f32x16 (&pre)[NP], float *s_w) {
+  float4 *dst = reinterpret_cast<float4 *>(s_w);
+#pragma unroll
+  for (int j = 0; j < FLOATS / (4 * MLP_WG); j++)
+    dst[(int)threadIdx.x + j * MLP_WG] = make_float4(pre[j / 4][4 * (j % 4)], pre[j / 4][4 * (j % 4) + 1], pre[j / 4][4 * (j % 4) + 2],
+                                                     pre[j / 4][4 * (j % 4) + 3]);
+}
+
 template <int L>
 __device__ __forceinline__ void mlp_stage(const float *packed, float *s_w) {
   mlp_stage_block<mlp_packed_offset(L), mlp_packed_floats(L)>(packed, s_w);
@@ -390,6 +416,7 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
   mlp_stage_bf16<0>(packed, s_w);
+  f32x16 pre[MLP_PRE];
   uint4 eh[2][2], el[2][2];
   {
     f32x16 emb[2];
@@ -399,24 +426,28 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   __syncthreads();
   f32x16 a[4];
   uint4 fh[4][2], fl[4][2];
+  mlp_prefetch<MLP_PACKED_FWD16 + mlp_packed_offset(1), mlp_packed_floats(1)>(packed, pre);
   mlp_layer_bf16<0, 2>(s_f, s_b, eh, el, a, lane);
   mlp_relu(a);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bf16<1>(packed, s_w);
+  mlp_commit<mlp_packed_floats(1)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_FWD16 + mlp_packed_offset(2), mlp_packed_floats(2)>(packed, pre);
   mlp_layer_bf16<1, 4>(s_f, s_b + MLP_W, fh, fl, a, lane);
   mlp_relu(a);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bf16<2>(packed, s_w);
+  mlp_commit<mlp_packed_floats(2)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_FWD16 + mlp_packed_offset(3), mlp_packed_floats(3)>(packed, pre);
   mlp_layer_bf16<2, 4>(s_f, s_b + 2 * MLP_W, fh, fl, a, lane);
   mlp_relu(a);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bf16<3>(packed, s_w);
+  mlp_commit<mlp_packed_floats(3)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_FWD16 + mlp_packed_offset(4), mlp_packed_floats(4)>(packed, pre);
   {
     uint4 ch[6][2], cl[6][2];
 #pragma unroll
@@ -432,7 +463,7 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   mlp_relu(a);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bf16<4>(packed, s_w);
+  mlp_commit<mlp_packed_floats(4)>(pre, s_w);
   __syncthreads();
   f32x16 o[1];
   mlp_layer_bf16<4, 4>(s_f, s_b + 4 * MLP_W, fh, fl, o, lane);
@@ -599,6 +630,7 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
   mlp_stage_bf16<0>(packed, s_w);
+  f32x16 pre[2];   // (two vectors = 64 KB per workgroup in flight: a third spills in this kernel; layer 3's last 32 KB are staged directly)
   uint4 eh[2][2], el[2][2];
   {
     f32x16 emb[2];
@@ -611,27 +643,32 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   f32x16 a[4];
   uint4 fh[4][2], fl[4][2];
   uint32_t m1[2], m2[2], m3[2], m4[2];
+  mlp_prefetch<MLP_PACKED_FWD16 + mlp_packed_offset(1), mlp_packed_floats(1)>(packed, pre);
   mlp_layer_bf16<0, 2>(s_f, s_b, eh, el, a, lane);
   mlp_relu_mask(a, m1);
   mlp_store_tiles<4>(ws, Pp, MLP_WS_H1, a, p, half);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bf16<1>(packed, s_w);
+  mlp_commit<mlp_packed_floats(1)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_FWD16 + mlp_packed_offset(2), mlp_packed_floats(2)>(packed, pre);
   mlp_layer_bf16<1, 4>(s_f, s_b + MLP_W, fh, fl, a, lane);
   mlp_relu_mask(a, m2);
   mlp_store_tiles<4>(ws, Pp, MLP_WS_H1 + MLP_W, a, p, half);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bf16<2>(packed, s_w);
+  mlp_commit<mlp_packed_floats(2)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_FWD16 + mlp_packed_offset(3), 16384>(packed, pre);
   mlp_layer_bf16<2, 4>(s_f, s_b + 2 * MLP_W, fh, fl, a, lane);
   mlp_relu_mask(a, m3);
   mlp_store_tiles<4>(ws, Pp, MLP_WS_H1 + 2 * MLP_W, a, p, half);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bf16<3>(packed, s_w);
+  mlp_commit<16384>(pre, s_w);
+  mlp_stage_block<MLP_PACKED_FWD16 + mlp_packed_offset(3) + 16384, mlp_packed_floats(3) - 16384>(packed, s_w + 16384);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_BWD16 + (mlp_bwd_offset(0) - MLP_PACKED), mlp_bwd_floats(0)>(packed, pre);
   {
     uint4 ch[6][2], cl[6][2];
 #pragma unroll
@@ -659,31 +696,34 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     mlp_split_tiles<1>(d, dh, dl);
   }
   __syncthreads();
-  mlp_stage_bwd16<0>(packed, s_w);
+  mlp_commit<mlp_bwd_floats(0)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_BWD16 + (mlp_bwd_offset(1) - MLP_PACKED), mlp_bwd_floats(1)>(packed, pre);
   mlp_zero(a);
   mlp_mm_bf16<1, 4>(s_f, dh, dl, a, lane);
   mlp_apply_mask(a, m4);
   mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + 3 * MLP_W, a, p, half);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bwd16<1>(packed, s_w);
+  mlp_commit<mlp_bwd_floats(1)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_BWD16 + (mlp_bwd_offset(2) - MLP_PACKED), mlp_bwd_floats(2)>(packed, pre);
   mlp_zero(a);
   mlp_mm_bf16<4, 4>(s_f, fh, fl, a, lane);
   mlp_apply_mask(a, m3);
   mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + 2 * MLP_W, a, p, half);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bwd16<2>(packed, s_w);
+  mlp_commit<mlp_bwd_floats(2)>(pre, s_w);
   __syncthreads();
+  mlp_prefetch<MLP_PACKED_BWD16 + (mlp_bwd_offset(3) - MLP_PACKED), mlp_bwd_floats(3)>(packed, pre);
   mlp_zero(a);
   mlp_mm_bf16<4, 4>(s_f, fh, fl, a, lane);
   mlp_apply_mask(a, m2);
   mlp_store_tiles<4>(ws, Pp, MLP_WS_DZ0 + MLP_W, a, p, half);
   mlp_split_tiles<4>(a, fh, fl);
   __syncthreads();
-  mlp_stage_bwd16<3>(packed, s_w);
+  mlp_commit<mlp_bwd_floats(3)>(pre, s_w);
   __syncthreads();
   mlp_zero(a);
   mlp_mm_bf16<4, 4>(s_f, fh, fl, a, lane);
