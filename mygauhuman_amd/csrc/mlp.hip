@@ -180,13 +180,35 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpWeights src, flo
   packed[e] = (col >= 0 && o < nrows) ? src.w[l][(size_t)o * ncols + col] : 0.f;
 }
 
-// embedding feature k (0..63; 63 = padding) of a point
+// embedding feature k (0..63; 63 = padding) of a point.  FAST (the bf16 kernels): sin / cos on the hardware instruction, which takes
+// REVOLUTIONS: the argument x 2^o is exact, its product with 1 / (2 pi) is formed in two terms (error ~1e-8 revolutions before the
+// fraction is taken), v_sin_f32 / v_cos_f32 add ~1e-6 -- a tenth of what that path's bf16 terms drop -- at a tenth of libm's ~120
+// instructions per value (32 values per lane were a quarter of the forward's time).  The f32 kernels keep sinf / cosf.
+template <bool FAST>
 __device__ __forceinline__ float mlp_embed(int k, float x, float y, float z) {
   if (k >= MLP_E) return 0.f;
   if (k < 3) return k == 0 ? x : (k == 1 ? y : z);
   const int t = k - 3, oct = t / 6, r = t % 6, c = r % 3;
   const float ang = (c == 0 ? x : (c == 1 ? y : z)) * (float)(1 << oct);
-  return r < 3 ? sinf(ang) : cosf(ang);
+  if constexpr (FAST) {
+    constexpr float INV2PI_HI = 0.15915494f, INV2PI_LO = (float)(0.15915494309189535 - (double)0.15915494f);
+    const float p_hi = ang * INV2PI_HI;
+    const float p_lo = __builtin_fmaf(ang, INV2PI_HI, -p_hi) + ang * INV2PI_LO;
+    const float rev = (p_hi - floorf(p_hi)) + p_lo;
+    return r < 3 ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
+  } else {
+    return r < 3 ? sinf(ang) : cosf(ang);
+  }
+}
+
+// the embedding as two activation tiles (features 0..31, 32..63); a template recursion: left as a loop the compiler does not unroll
+// the 32 inlined sin / cos evaluations and puts the tile array into scratch
+template <bool FAST, int K = 0>
+__device__ __forceinline__ void mlp_embed_tiles(f32x16 (&emb)[2], int half, float x, float y, float z) {
+  if constexpr (K < 32) {
+    emb[K / 16][K % 16] = mlp_embed<FAST>(32 * (K / 16) + mlp_row_of_reg(K % 16) + 4 * half, x, y, z);
+    mlp_embed_tiles<FAST, K + 1>(emb, half, x, y, z);
+  }
 }
 
 // out[to] += A-fragments(s_w) x in[ti]: NTI input tiles (32 features each) -> NTO output tiles, 16 k-steps per input tile
@@ -208,16 +230,6 @@ __device__ __forceinline__ void mlp_mm(const float *s_w, const f32x16 (&in)[NTI]
         out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[ti][i], out[0], 0, 0, 0);
       }
     }
-  }
-}
-
-// the embedding as two activation tiles (features 0..31, 32..63); a template recursion: left as a loop the compiler does not unroll
-// the 32 inlined sin / cos evaluations and puts the tile array into scratch
-template <int K = 0>
-__device__ __forceinline__ void mlp_embed_tiles(f32x16 (&emb)[2], int half, float x, float y, float z) {
-  if constexpr (K < 32) {
-    emb[K / 16][K % 16] = mlp_embed(32 * (K / 16) + mlp_row_of_reg(K % 16) + 4 * half, x, y, z);
-    mlp_embed_tiles<K + 1>(emb, half, x, y, z);
   }
 }
 
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
   mlp_stage<0>(packed, s_w);
   f32x16 emb[2];
-  mlp_embed_tiles(emb, (int)half, x, y, z);
+  mlp_embed_tiles<false>(emb, (int)half, x, y, z);
   __syncthreads();
   f32x16 a[4], b[4];
   mlp_layer<0, 2>(s_w, s_b, emb, a, lane);
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   uint4 eh[2][2], el[2][2];
   {
     f32x16 emb[2];
-    mlp_embed_tiles(emb, (int)half, x, y, z);
+    mlp_embed_tiles<true>(emb, (int)half, x, y, z);
     mlp_split_tiles<2>(emb, eh, el);
   }
   __syncthreads();
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (int q = threadIdx.x; q < MLP_PACKED_B; q += MLP_WG) s_b[q] = packed[MLP_PACKED_W + q];
   mlp_stage<0>(packed, s_w);
   f32x16 emb[2];
-  mlp_embed_tiles(emb, (int)half, x, y, z);
+  mlp_embed_tiles<false>(emb, (int)half, x, y, z);
   mlp_store_tiles<2>(ws, Pp, MLP_WS_EMB, emb, p, half);
   __syncthreads();
   // ---- the forward again: outputs to the workspace, masks to registers
@@ -634,7 +646,7 @@ __global__ __launch_bounds__(MLP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   uint4 eh[2][2], el[2][2];
   {
     f32x16 emb[2];
-    mlp_embed_tiles(emb, (int)half, x, y, z);
+    mlp_embed_tiles<true>(emb, (int)half, x, y, z);
     mlp_store_tiles<2>(ws, Pp, MLP_WS_EMB, emb, p, half);
     mlp_split_tiles<2>(emb, eh, el);
   }
