@@ -121,7 +121,13 @@ class _FusedOffsetNet(torch.autograd.Function):
         x, packed = ctx.saved_tensors
         dev, P = x.device, x.shape[0]
         g = g.contiguous().float()
-        grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
+        # one zero fill for the ten gradient tensors (the kernels ADD into them): views of one flat buffer
+        sizes = [int(torch.Size(s).numel()) for s in ctx.shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for shp, n in zip(ctx.shapes, sizes):
+            grads.append(flat[off:off + n].view(shp))
+            off += n
         ws = torch.empty(int(lib.gsr_lbs_offset_mlp_backward_workspace_floats(P)), dtype=torch.float32, device=dev)
         mk = lambda xs: (C.c_void_p * 5)(*[t.data_ptr() for t in xs])  # noqa: E731
         with torch.cuda.device(dev):
